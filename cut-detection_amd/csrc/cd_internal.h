@@ -1,0 +1,96 @@
+// Internal declarations shared by the translation units of libcutdet.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdarg.h>
+
+#include "../../include/cutdet.h"
+
+namespace cd {
+
+// ---- network geometry (prod_net; input width is fixed at 256) ---------------------------------
+constexpr int kC = 48;          // channels of every conv layer's output
+constexpr int kInC = 3;         // RGB
+constexpr int kNetW = 256;      // network input width
+constexpr int kW1 = 85;         // width after block 1  (256 / 3)
+constexpr int kW2 = 28;         // width after block 2  (85 / 3)
+constexpr int kW3 = 9;          // width after block 3  (28 / 3)
+constexpr int kPool = 4;        // adaptive average pool output size
+constexpr int kFeat = kC * kPool * kPool;   // 768
+constexpr int kHid = 32;
+constexpr int kOut = 3;
+constexpr int kMaxSrcW = 8192;  // widest source frame the resize tables are sized for
+constexpr int kMaxNetH = 224;   // tallest network input the head kernel's LDS tile holds
+
+struct Geometry {               // per network-input height
+    int h, h1, h2, h3;          // input rows, rows after each conv block
+};
+inline Geometry geometry(int h) { Geometry g; g.h = h; g.h1 = h / 3; g.h2 = g.h1 / 3; g.h3 = g.h2 / 3; return g; }
+
+// ---- resize tables (device) -------------------------------------------------------------------
+struct ResizeTables {
+    int* sx;  short* ax;   // [w] left sample column; [2w] 11-bit coefficient pairs
+    int* sy;  short* by;   // [h] top sample row (unclamped); [2h] coefficient pairs
+    int mode;              // 0 bilinear fixed point, 1 pure point sample, 2 exact 2x2 box
+    int H0, W0, h, w;      // geometry the tables currently describe (0 = none)
+};
+
+// ---- packed parameters on the device ----------------------------------------------------------
+struct DeviceParams {
+    float* w1;    // conv1 B fragments  [7 k-steps][3 n-tiles][64 lanes]
+    float* w2;    // conv2 B fragments  [27 steps][3 n-tiles][64 lanes][4]
+    float* w3;    // conv3 B fragments  (same layout as w2)
+    float* post;  // [3 layers][3][48]: conv bias, BN scale, BN shift
+    float* fc0w;  // [32][768]
+    float* fc0p;  // [3][32]: bias, BN scale, BN shift
+    float* fc1w;  // [3][32]
+    float* fc1b;  // [3]
+    float* lut;   // [256] k/255 in fp32 (correctly rounded division)
+};
+
+}  // namespace cd
+
+struct cd_handle {
+    int device;
+    int dtype;
+    cd::DeviceParams p;
+    cd::ResizeTables rt;
+    void* table_mem;        // one allocation behind rt.*
+    void* param_mem;        // one allocation behind p.*
+    float* act1;            // workspace: [frames][h1][85][48]
+    float* act2;            // workspace: [frames][h2][28][48]
+    size_t act1_bytes, act2_bytes;
+    int64_t* rle_blocks;    // workspace of cd_rle: per-block boundary counts / offsets
+    int rle_blocks_cap;
+};
+
+namespace cd {
+
+void set_error(const char* fmt, ...);
+#define CD_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            cd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return CD_EHIP;                                                               \
+        }                                                                                 \
+    } while (0)
+
+// kernel launchers (each queues work on `s` and returns a CD_* code)
+int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                      int64_t frame_stride, int chan_order, float* dst, int nh, int nw, hipStream_t s);
+int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s);
+int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                    int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s);
+int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s);
+int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logits, float* maxv,
+                      int64_t* argmax, hipStream_t s);
+int launch_rle(const cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset,
+               int64_t* end, int64_t* type, int64_t* runlen, int64_t* start, float* mean, double* sum,
+               int64_t cap, int64_t* n_seg, hipStream_t s);
+int launch_max_argmax(const float* scores, int64_t n, int ncls, float* maxv, int64_t* argmax, hipStream_t s);
+int launch_synth(uint8_t* dst, int n, int H0, int W0, const uint8_t* classes, uint32_t seed,
+                 int64_t first_index, hipStream_t s);
+
+}  // namespace cd

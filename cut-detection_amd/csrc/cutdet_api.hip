@@ -1,0 +1,380 @@
+// C ABI of libcutdet.so: handle management, parameter packing, argument checks.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "cd_internal.h"
+
+namespace cd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+constexpr char kMagic[8] = {'C', 'D', 'N', 'E', 'T', 'W', '1', '\0'};
+constexpr size_t kHeader = 8 + 8 * 4;
+
+struct ConvHost { const float *w, *b, *g, *beta, *mu, *var; };
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// BatchNorm(eval) as the affine y = x*scale + shift, evaluated in fp32 in the order torch's CPU
+// kernel uses: invstd = 1/sqrt(var+eps); scale = invstd*gamma; shift = beta - mean*scale.
+void bn_affine(const float* g, const float* beta, const float* mu, const float* var, int n, float* scale,
+               float* shift) {
+    for (int c = 0; c < n; ++c) {
+        float invstd = 1.0f / std::sqrt(var[c] + 1e-5f);
+        scale[c] = invstd * g[c];
+        shift[c] = beta[c] - mu[c] * scale[c];
+    }
+}
+
+struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut; };
+
+// Packs everything the kernels read into one host image; `off` receives where each section
+// starts (in floats) so the caller can rebase them onto the device allocation.
+std::vector<float> pack_params(const float* f, ParamOffsets* off) {
+    ConvHost cv[3];
+    const float* cur = f;
+    int cin = kInC;
+    for (int l = 0; l < 3; ++l) {
+        cv[l].w = cur; cur += (size_t)kC * cin * 9;
+        cv[l].b = cur; cur += kC;
+        cv[l].g = cur; cur += kC;
+        cv[l].beta = cur; cur += kC;
+        cv[l].mu = cur; cur += kC;
+        cv[l].var = cur; cur += kC;
+        cin = kC;
+    }
+    const float* fc0w = cur; cur += (size_t)kHid * kFeat;
+    const float* fc0b = cur; cur += kHid;
+    const float* fc0g = cur; cur += kHid;
+    const float* fc0beta = cur; cur += kHid;
+    const float* fc0mu = cur; cur += kHid;
+    const float* fc0var = cur; cur += kHid;
+    const float* fc1w = cur; cur += (size_t)kOut * kHid;
+    const float* fc1b = cur;
+
+    std::vector<float> img;
+    auto section = [&](size_t n) { size_t at = align_up(img.size(), 64); img.resize(at + n, 0.f); return at; };
+    const size_t o_w1 = section(7 * 3 * 64);
+    const size_t o_w2 = section(27 * 3 * 64 * 4);
+    const size_t o_w3 = section(27 * 3 * 64 * 4);
+    const size_t o_post = section(3 * 3 * kC);
+    const size_t o_fc0w = section((size_t)kHid * kFeat);
+    const size_t o_fc0p = section(3 * kHid);
+    const size_t o_fc1w = section(kOut * kHid);
+    const size_t o_fc1b = section(kOut);
+    const size_t o_lut = section(256);
+
+    // block 1 B fragments: lane (kq = lane>>4, col = lane&15) of k-step s holds W[16nt+col][4s+kq]
+    for (int s = 0; s < 7; ++s)
+        for (int nt = 0; nt < 3; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                int k = 4 * s + (lane >> 4), oc = 16 * nt + (lane & 15);
+                img[o_w1 + (s * 3 + nt) * 64 + lane] = k < 27 ? cv[0].w[oc * 27 + k] : 0.f;
+            }
+    // blocks 2/3: step (ky, kx, g), k-step e covers input channel 16g + 4kq + e
+    for (int l = 1; l < 3; ++l) {
+        const size_t o = l == 1 ? o_w2 : o_w3;
+        for (int kk = 0; kk < 9; ++kk)
+            for (int g = 0; g < 3; ++g)
+                for (int nt = 0; nt < 3; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            int ci = 16 * g + 4 * (lane >> 4) + e, oc = 16 * nt + (lane & 15);
+                            img[o + ((((size_t)(kk * 3 + g) * 3 + nt) * 64 + lane) * 4) + e] =
+                                cv[l].w[((size_t)oc * kC + ci) * 9 + kk];
+                        }
+    }
+    for (int l = 0; l < 3; ++l) {
+        float* p = &img[o_post + (size_t)l * 3 * kC];
+        std::memcpy(p, cv[l].b, kC * sizeof(float));
+        bn_affine(cv[l].g, cv[l].beta, cv[l].mu, cv[l].var, kC, p + kC, p + 2 * kC);
+    }
+    std::memcpy(&img[o_fc0w], fc0w, (size_t)kHid * kFeat * sizeof(float));
+    std::memcpy(&img[o_fc0p], fc0b, kHid * sizeof(float));
+    bn_affine(fc0g, fc0beta, fc0mu, fc0var, kHid, &img[o_fc0p + kHid], &img[o_fc0p + 2 * kHid]);
+    std::memcpy(&img[o_fc1w], fc1w, kOut * kHid * sizeof(float));
+    std::memcpy(&img[o_fc1b], fc1b, kOut * sizeof(float));
+    for (int k = 0; k < 256; ++k) img[o_lut + k] = (float)k / 255.0f;   // data.py:227 divides, it does not scale
+
+    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut};
+    return img;
+}
+
+// One axis of OpenCV's 8U INTER_LINEAR tables (float/double mix as in resize.cpp).
+void axis_tables(int src_n, int dst_n, bool zero_at_border, std::vector<int>& s, std::vector<short>& c) {
+    const double inv = (double)dst_n / src_n, scale = 1.0 / inv;
+    s.resize(dst_n);
+    c.resize(2 * (size_t)dst_n);
+    for (int d = 0; d < dst_n; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int i = (int)std::floor(f);
+        f -= (float)i;
+        if (zero_at_border) {
+            if (i < 0) { f = 0.f; i = 0; }
+            if (i >= src_n - 1) { f = 0.f; i = src_n - 1; }
+        }
+        long c0 = lrintf((1.f - f) * 2048.f), c1 = lrintf(f * 2048.f);
+        s[d] = i;
+        c[2 * d] = (short)std::min(32767l, std::max(-32768l, c0));
+        c[2 * d + 1] = (short)std::min(32767l, std::max(-32768l, c1));
+    }
+}
+
+int ensure_tables(cd_handle* h, int H0, int W0, int nh, int nw, hipStream_t s) {
+    ResizeTables& rt = h->rt;
+    if (rt.H0 == H0 && rt.W0 == W0 && rt.h == nh && rt.w == nw) return CD_OK;
+    if (H0 < 1 || W0 < 1 || nh < 1 || nw < 1 || W0 > kMaxSrcW || H0 > kMaxSrcW || nh > kMaxSrcW || nw > kMaxSrcW) {
+        set_error("resize %dx%d -> %dx%d outside the supported range (1..%d per side)", W0, H0, nw, nh, kMaxSrcW);
+        return CD_EINVAL;
+    }
+    std::vector<int> sx, sy;
+    std::vector<short> ax, by;
+    axis_tables(W0, nw, true, sx, ax);
+    axis_tables(H0, nh, false, sy, by);
+    int mode = 0;
+    if (H0 == 2 * nh && W0 == 2 * nw) mode = 2;
+    else {
+        bool point = true;
+        for (int x = 0; x < nw; ++x) point &= ax[2 * x + 1] == 0 && ax[2 * x] == 2048;
+        for (int y = 0; y < nh; ++y) point &= by[2 * y + 1] == 0 && by[2 * y] == 2048 && sy[y] >= 0 && sy[y] < H0;
+        if (point) mode = 1;
+    }
+    // Tables of the previous geometry may still be in use by queued kernels.
+    CD_HIP(hipStreamSynchronize(s));
+    CD_HIP(hipMemcpy(rt.sx, sx.data(), sx.size() * sizeof(int), hipMemcpyHostToDevice));
+    CD_HIP(hipMemcpy(rt.ax, ax.data(), ax.size() * sizeof(short), hipMemcpyHostToDevice));
+    CD_HIP(hipMemcpy(rt.sy, sy.data(), sy.size() * sizeof(int), hipMemcpyHostToDevice));
+    CD_HIP(hipMemcpy(rt.by, by.data(), by.size() * sizeof(short), hipMemcpyHostToDevice));
+    rt.mode = mode; rt.H0 = H0; rt.W0 = W0; rt.h = nh; rt.w = nw;
+    return CD_OK;
+}
+
+int ensure_workspace(cd_handle* h, int n, const Geometry& g, hipStream_t s) {
+    const size_t need1 = (size_t)n * g.h1 * kW1 * kC * sizeof(float);
+    const size_t need2 = (size_t)n * g.h2 * kW2 * kC * sizeof(float);
+    if (need1 <= h->act1_bytes && need2 <= h->act2_bytes) return CD_OK;
+    CD_HIP(hipStreamSynchronize(s));
+    if (need1 > h->act1_bytes) {
+        if (h->act1) CD_HIP(hipFree(h->act1));
+        h->act1 = nullptr; h->act1_bytes = 0;
+        CD_HIP(hipMalloc(reinterpret_cast<void**>(&h->act1), need1));
+        h->act1_bytes = need1;
+    }
+    if (need2 > h->act2_bytes) {
+        if (h->act2) CD_HIP(hipFree(h->act2));
+        h->act2 = nullptr; h->act2_bytes = 0;
+        CD_HIP(hipMalloc(reinterpret_cast<void**>(&h->act2), need2));
+        h->act2_bytes = need2;
+    }
+    return CD_OK;
+}
+
+int check_net_shape(int n, int net_h, int net_w, Geometry* g) {
+    if (n < 1) { set_error("batch of %d frames", n); return CD_EINVAL; }
+    if (net_w != kNetW) { set_error("network input width must be %d, got %d", kNetW, net_w); return CD_EINVAL; }
+    *g = geometry(net_h);
+    if (g->h3 < 1 || net_h > kMaxNetH) {
+        set_error("network input height %d unsupported (27..%d rows)", net_h, kMaxNetH);
+        return CD_EINVAL;
+    }
+    return CD_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+}  // namespace cd
+
+using namespace cd;
+
+extern "C" {
+
+int cd_version(void) { return 1; }
+
+const char* cd_last_error(void) { return cd::g_err; }
+
+int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int device, int dtype) {
+    if (!out || !weights_blob) { set_error("cd_create: null argument"); return CD_EINVAL; }
+    *out = nullptr;
+    if (dtype != CD_F32) { set_error("cd_create: dtype %d not supported (0 = f32)", dtype); return CD_EINVAL; }
+    const unsigned char* b = static_cast<const unsigned char*>(weights_blob);
+    if (nbytes < kHeader || std::memcmp(b, kMagic, 8) != 0) { set_error("cd_create: not a weight blob"); return CD_EINVAL; }
+    uint32_t hd[8];
+    std::memcpy(hd, b + 8, sizeof hd);
+    const uint32_t want_floats = (kC * kInC * 9 + 5 * kC) + 2 * (kC * kC * 9 + 5 * kC) +
+                                 (kHid * kFeat + 5 * kHid) + (kOut * kHid + kOut);
+    if (hd[0] != 1 || hd[1] != 3 || hd[2] != (uint32_t)kC || hd[3] != (uint32_t)kInC || hd[4] != (uint32_t)kPool ||
+        hd[5] != (uint32_t)kHid || hd[6] != (uint32_t)kOut || hd[7] != want_floats ||
+        nbytes != kHeader + (size_t)want_floats * 4) {
+        set_error("cd_create: blob is not a version-1 prod_net (3 conv x 48 ch, pool 4, 32 hidden, 3 classes)");
+        return CD_EINVAL;
+    }
+    int ndev = 0;
+    CD_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { set_error("cd_create: device %d of %d", device, ndev); return CD_EINVAL; }
+    DeviceGuard guard(device);
+    if (!guard.ok) { set_error("cd_create: cannot select device %d", device); return CD_EHIP; }
+
+    std::vector<float> f(want_floats);
+    std::memcpy(f.data(), b + kHeader, (size_t)want_floats * 4);
+    cd_handle* h = new (std::nothrow) cd_handle();
+    if (!h) { set_error("cd_create: out of host memory"); return CD_ENOMEM; }
+    std::memset(h, 0, sizeof *h);
+    h->device = device;
+    h->dtype = dtype;
+    ParamOffsets off;
+    std::vector<float> img = pack_params(f.data(), &off);
+    auto fail = [&](int code) { cd_destroy(h); return code; };
+#define CD_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(CD_EHIP); } } while (0)
+    CD_TRY(hipMalloc(&h->param_mem, img.size() * sizeof(float)));
+    CD_TRY(hipMemcpy(h->param_mem, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    float* base = static_cast<float*>(h->param_mem);
+    h->p.w1 = base + off.w1; h->p.w2 = base + off.w2; h->p.w3 = base + off.w3; h->p.post = base + off.post;
+    h->p.fc0w = base + off.fc0w; h->p.fc0p = base + off.fc0p; h->p.fc1w = base + off.fc1w;
+    h->p.fc1b = base + off.fc1b; h->p.lut = base + off.lut;
+
+    const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);
+    const size_t t_short = align_up((size_t)2 * kMaxSrcW * sizeof(short), 256);
+    CD_TRY(hipMalloc(&h->table_mem, 2 * t_int + 2 * t_short));
+    char* t = static_cast<char*>(h->table_mem);
+    h->rt.sx = reinterpret_cast<int*>(t); t += t_int;
+    h->rt.sy = reinterpret_cast<int*>(t); t += t_int;
+    h->rt.ax = reinterpret_cast<short*>(t); t += t_short;
+    h->rt.by = reinterpret_cast<short*>(t);
+    h->rle_blocks_cap = 1 << 16;   // x 4096 frames per block
+    CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->rle_blocks), (size_t)h->rle_blocks_cap * sizeof(int64_t)));
+#undef CD_TRY
+    *out = h;
+    return CD_OK;
+}
+
+void cd_destroy(cd_handle* h) {
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    if (h->param_mem) (void)hipFree(h->param_mem);
+    if (h->table_mem) (void)hipFree(h->table_mem);
+    if (h->act1) (void)hipFree(h->act1);
+    if (h->act2) (void)hipFree(h->act2);
+    if (h->rle_blocks) (void)hipFree(h->rle_blocks);
+    delete h;
+}
+
+int cd_reserve(cd_handle* h, int max_frames, int net_h) {
+    if (!h) { set_error("cd_reserve: null handle"); return CD_EINVAL; }
+    Geometry g;
+    int rc = check_net_shape(max_frames, net_h, kNetW, &g);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    return ensure_workspace(h, max_frames, g, nullptr);
+}
+
+static int check_src(const char* who, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                     int64_t frame_stride, int chan_order) {
+    if (!src || n < 1) { set_error("%s: null source or empty batch", who); return CD_EINVAL; }
+    if (chan_order != CD_BGR && chan_order != CD_RGB) { set_error("%s: chan_order %d", who, chan_order); return CD_EINVAL; }
+    if (H0 < 1 || W0 < 1 || row_stride < (int64_t)W0 * 3 || frame_stride < row_stride * H0) {
+        set_error("%s: strides (%lld, %lld) too small for %dx%d frames", who, (long long)row_stride,
+                  (long long)frame_stride, W0, H0);
+        return CD_EINVAL;
+    }
+    return CD_OK;
+}
+
+int cd_preprocess(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                  int64_t frame_stride, int chan_order, float* dst, int net_h, int net_w, void* stream) {
+    if (!h || !dst) { set_error("cd_preprocess: null argument"); return CD_EINVAL; }
+    int rc = check_src("cd_preprocess", src, n, H0, W0, row_stride, frame_stride, chan_order);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;
+    return launch_preprocess(h, src, n, H0, W0, row_stride, frame_stride, chan_order, dst, net_h, net_w, s);
+}
+
+int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w, float* logits, float* maxv,
+               int64_t* argmax, void* stream) {
+    if (!h || !x || !logits) { set_error("cd_forward: null argument"); return CD_EINVAL; }
+    Geometry g;
+    int rc = check_net_shape(n, net_h, net_w, &g);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = ensure_workspace(h, n, g, s))) return rc;
+    if ((rc = launch_conv1_f32(h, x, n, g, s))) return rc;
+    if ((rc = launch_conv2(h, n, g, s))) return rc;
+    return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
+}
+
+int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                  int64_t frame_stride, int chan_order, int net_h, int net_w, float* logits, float* maxv,
+                  int64_t* argmax, void* stream) {
+    if (!h || !logits) { set_error("cd_forward_u8: null argument"); return CD_EINVAL; }
+    int rc = check_src("cd_forward_u8", src, n, H0, W0, row_stride, frame_stride, chan_order);
+    if (rc) return rc;
+    Geometry g;
+    if ((rc = check_net_shape(n, net_h, net_w, &g))) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;
+    if ((rc = ensure_workspace(h, n, g, s))) return rc;
+    if ((rc = launch_conv1_u8(h, src, n, H0, W0, row_stride, frame_stride, chan_order, g, s))) return rc;
+    if ((rc = launch_conv2(h, n, g, s))) return rc;
+    return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
+}
+
+int cd_rle(cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset, int64_t* end,
+           int64_t* type, int64_t* runlen, int64_t* start, float* mean, double* sum, int64_t cap,
+           int64_t* n_seg, void* stream) {
+    if (!h || !cls || !maxv || !end || !type || !runlen || !start || !mean || !n_seg) {
+        set_error("cd_rle: null argument");
+        return CD_EINVAL;
+    }
+    if (n < 1) { set_error("cd_rle: no frames (index out of bounds)"); return CD_EINVAL; }
+    if (cap < 1) { set_error("cd_rle: capacity %lld", (long long)cap); return CD_ECAP; }
+    DeviceGuard guard(h->device);
+    return launch_rle(h, cls, maxv, n, frame_offset, end, type, runlen, start, mean, sum, cap, n_seg,
+                      static_cast<hipStream_t>(stream));
+}
+
+int cd_max_argmax(cd_handle* h, const float* scores, int64_t n, int n_classes, float* maxv, int64_t* argmax,
+                  void* stream) {
+    if (!h || !scores || !maxv || !argmax || n < 1 || n_classes < 1) {
+        set_error("cd_max_argmax: null argument or empty input");
+        return CD_EINVAL;
+    }
+    DeviceGuard guard(h->device);
+    return launch_max_argmax(scores, n, n_classes, maxv, argmax, static_cast<hipStream_t>(stream));
+}
+
+int cd_synth_frames(cd_handle* h, uint8_t* dst, int n, int H0, int W0, const uint8_t* classes, uint32_t seed,
+                    int64_t first_index, void* stream) {
+    if (!h || !dst || !classes || n < 1 || n > 65535 || H0 < 1 || W0 < 1) {
+        set_error("cd_synth_frames: bad argument (1..65535 frames per call)");
+        return CD_EINVAL;
+    }
+    DeviceGuard guard(h->device);
+    return launch_synth(dst, n, H0, W0, classes, seed, first_index, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

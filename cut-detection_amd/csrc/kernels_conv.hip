@@ -1,0 +1,427 @@
+// prod_net forward: three fused conv3x3 -> ReLU -> maxpool3 -> BatchNorm blocks and the head.
+//
+// Every convolution is an implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16], exact fp32 fma chain):
+//     M = output pixels, N = output channels (48 = 3 tiles of 16), K = (ci, ky, kx).
+// Operand lane maps:  A: lane l holds A[row l&15][k l>>4];  B: lane l holds B[k l>>4][col l&15];
+//                     D: lane l holds D[row 4*(l>>4)+r][col l&15] in register r (r = 0..3).
+//
+// The unit of work is a WAVE TILE: 16 max-pool windows x 48 channels, i.e. 144 conv pixels =
+// 9 M-tiles (t = conv row inside the pool row, j = group of 4 columns) x 3 N-tiles = 27
+// accumulators.  M-row m = 4q + r of tile (t, j) is mapped to the conv pixel in pool-row slot q,
+// conv row t, column 4j + r of that slot's 12 columns, so that the four registers of lane
+// (q, channel) across the nine tiles hold exactly the 3x3 windows of 4 pool outputs: ReLU, the
+// 3x3 max, the bias and the BatchNorm affine all happen in registers and only the pooled
+// tensor is ever written (the reference materialises the full conv output, net.py:35-38).
+//
+// Activations between blocks are channel-last ([frame][row][col][48] fp32) so that one 16-byte
+// LDS read gives a lane the A values of four consecutive k-steps.
+#include "cd_sample.h"
+
+namespace cd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Pool-window max of one lane: columns 3*wi .. 3*wi+2 of its 12 columns, rows t = 0..2.
+// Column c12 lives in tile j = c12 >> 2, register r = c12 & 3.
+template <int WI>
+__device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3][3], int nt) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int c = 3 * WI; c < 3 * WI + 3; ++c) m = fmaxf(m, acc[t][c >> 2][nt][c & 3]);
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------
+// Block 1: 3 -> 48 channels, K = 27 (padded to 28 = 7 k-steps).
+// One workgroup (4 waves) = 3 pooled rows of one frame = 255 pool windows = 16 wave tiles
+// (windows enumerated row-major, 16 per tile; only the 256th is padding).  The 11 input rows
+// x 258 columns x 3 channels the tile needs are staged in LDS as fp32, either copied from the
+// normalised NCHW tensor (MODE 0) or produced on the fly from the u8 source frame by the
+// fixed-point bilinear resize (MODE 1), so the resized frame never exists in HBM.
+// ------------------------------------------------------------------------------------------
+constexpr int kC1Rows = 11;
+constexpr int kC1RS = 260;                 // LDS row stride (floats); columns -1 .. 256 used
+constexpr int kC1Tile = kInC * kC1Rows * kC1RS;
+constexpr int kC1PoolRows = 3;
+constexpr int kC1Windows = kC1PoolRows * kW1;   // 255
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv1_kernel(
+    const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
+    int chan_order, const float* __restrict__ lut, const float* __restrict__ wfrag,
+    const float* __restrict__ post, float* __restrict__ out, int H, int Hp, int chunks) {
+    __shared__ float tile[kC1Tile];
+    __shared__ float slut[MODE == 1 ? 256 : 1];
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x / chunks;
+    const int py0 = (blockIdx.x % chunks) * kC1PoolRows;
+    const int gy0 = 3 * py0 - 1;           // input row held in LDS row 0
+
+    if (MODE == 1) { slut[tid] = lut[tid]; __syncthreads(); }
+    if (MODE == 0) {
+        const float* fx = x + (int64_t)frame * kInC * H * kNetW;
+        for (int idx = tid; idx < kInC * kC1Rows * 258; idx += 256) {
+            int c = idx % 258, rr = idx / 258;
+            int r = rr % kC1Rows, ci = rr / kC1Rows;
+            int gy = gy0 + r, gx = c - 1;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < kNetW) v = fx[((int64_t)ci * H + gy) * kNetW + gx];
+            tile[(ci * kC1Rows + r) * kC1RS + c] = v;
+        }
+    } else {
+        const uint8_t* fsrc = src + (int64_t)frame * frame_stride;
+        for (int idx = tid; idx < kC1Rows * 258; idx += 256) {
+            int c = idx % 258, r = idx / 258;
+            int gy = gy0 + r, gx = c - 1;
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < kNetW;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                float v = 0.f;
+                if (inside) v = slut[sample_u8(fsrc, gy, gx, chan_order == CD_BGR ? 2 - ci : ci, sa)];
+                tile[(ci * kC1Rows + r) * kC1RS + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, kq = lane >> 4;
+
+    // B fragments for all 7 k-steps stay in registers for the whole workgroup.
+    float bw[7][3];
+    int koff[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) bw[s][nt] = wfrag[(s * 3 + nt) * 64 + lane];
+        int k = min(4 * s + kq, 26);       // k = 27 is padding: its weight is 0, read a valid cell
+        int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
+        koff[s] = (ci * kC1Rows + ky) * kC1RS + kx;
+    }
+
+    const int q = lane >> 4, ch = lane & 15;
+    for (int wt = wave; wt < 16; wt += 4) {
+        const int w0 = wt * 16;
+        int base[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int c12 = 4 * j + (i & 3);
+            int W = min(w0 + 4 * (i >> 2) + c12 / 3, kC1Windows - 1);
+            int wrow = W / kW1, px = W % kW1;
+            base[j] = (3 * wrow) * kC1RS + 3 * px + c12 % 3;
+        }
+        f32x4 acc[3][3][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            float a[3][3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[t][j] = tile[base[j] + koff[s] + t * kC1RS];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = mfma4(a[t][j], bw[s][nt], acc[t][j][nt]);
+        }
+        // epilogue: lane (q, ch) owns pool windows w0 + 4q .. w0 + 4q + 3 for channels ch + 16 nt
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int c = nt * 16 + ch;
+            const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
+            float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
+                          window_max<3>(acc, nt)};
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) {
+                int W = w0 + 4 * q + wi;
+                int py = py0 + W / kW1, px = W % kW1;
+                if (W < kC1Windows && py < Hp) {
+                    float v = fmaxf(m[wi] + bias, 0.f);
+                    out[(((int64_t)frame * Hp + py) * kW1 + px) * kC + c] = fmaf(v, sc, sh);
+                }
+            }
+        }
+    }
+}
+
+int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s) {
+    const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
+    SampleArgs sa{};
+    hipLaunchKernelGGL(conv1_kernel<0>, dim3((unsigned)(n * chunks)), dim3(256), 0, s, x,
+                       (const uint8_t*)nullptr, sa, (int64_t)0, 0, (const float*)nullptr, h->p.w1, h->p.post,
+                       h->act1, g.h, g.h1, chunks);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                    int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s) {
+    const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
+    SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride};
+    hipLaunchKernelGGL(conv1_kernel<1>, dim3((unsigned)(n * chunks)), dim3(256), 0, s, (const float*)nullptr,
+                       src, sa, frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->act1, g.h, g.h1,
+                       chunks);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// 48 -> 48 channel wave tile (blocks 2 and 3), K = 432 = 27 steps of (ky, kx, 16-channel group)
+// x 4 k-steps.  `patch` is channel-last fp32 in LDS with pixel stride kC floats; a lane's A
+// values for the 4 k-steps of a step are one ds_read_b128 at
+//     patch[base[j] + ((t + ky) * pitch + kx) * kC + 16 g],   base[j] includes 4 * (lane >> 4).
+// k-step e of step (ky, kx, g) therefore covers input channels 16 g + 4 kq + e (kq = 0..3);
+// the packed weights use the same order.  wl points at this lane's first B fragment.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (&base)[3], int pitch,
+                                                 const f32x4* __restrict__ wl, f32x4 (&acc)[3][3][3]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kk = 0; kk < 9; ++kk) {
+        const int kkoff = ((kk / 3) * pitch + (kk % 3)) * kC;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            f32x4 b[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) b[nt] = wl[((kk * 3 + g) * 3 + nt) * 64];
+            f32x4 a[3][3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    a[t][j] = *reinterpret_cast<const f32x4*>(patch + base[j] + kkoff + t * pitch * kC + 16 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < 3; ++nt)
+                            acc[t][j][nt] = mfma4(a[t][j][e], b[nt][e], acc[t][j][nt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Block 2: one single-wave workgroup per 4x4 block of pool windows (12x12 conv pixels).
+// The 14x14x48 input patch (37.6 KB) is staged once; four such workgroups share a CU, one
+// wave per SIMD, each issuing 2916 back-to-back MFMAs per tile.
+// ------------------------------------------------------------------------------------------
+constexpr int kP2 = 14;
+
+__global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                   const float* __restrict__ wfrag,
+                                                   const float* __restrict__ post, int Hin, int Win, int Hp,
+                                                   int Wp, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float patch[kP2 * kP2 * kC];
+    const int lane = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int frame = blockIdx.x / tiles;
+    const int tt = blockIdx.x % tiles;
+    const int ty = tt / tiles_x, tx = tt % tiles_x;
+    const int y0 = ty * 12 - 1, x0 = tx * 12 - 1;
+    const float* fin = in + (int64_t)frame * Hin * Win * kC;
+
+    for (int idx = lane; idx < kP2 * kP2 * (kC / 4); idx += 64) {
+        int pix = idx / (kC / 4), c4 = idx % (kC / 4);
+        int gy = y0 + pix / kP2, gx = x0 + pix % kP2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win)
+            v = *reinterpret_cast<const f32x4*>(fin + ((int64_t)gy * Win + gx) * kC + 4 * c4);
+        *reinterpret_cast<f32x4*>(patch + pix * kC + 4 * c4) = v;
+    }
+    __syncthreads();
+
+    const int i = lane & 15, kq = lane >> 4;
+    int base[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * kC + 4 * kq;
+    f32x4 acc[3][3][3];
+    conv48_wave_tile(patch, base, kP2, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
+
+    const int q = lane >> 4, ch = lane & 15;
+    const int py = ty * 4 + q;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int c = nt * 16 + ch;
+        const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
+        float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
+                      window_max<3>(acc, nt)};
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi) {
+            int px = tx * 4 + wi;
+            if (py < Hp && px < Wp) {
+                float v = fmaxf(m[wi] + bias, 0.f);
+                out[(((int64_t)frame * Hp + py) * Wp + px) * kC + c] = fmaf(v, sc, sh);
+            }
+        }
+    }
+}
+
+int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
+    const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
+    hipLaunchKernelGGL(conv2_kernel, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(64), 0, s, h->act1, h->act2,
+                       h->p.w2, h->p.post + 3 * kC, g.h1, kW1, g.h2, kW2, tiles_x, tiles_y);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Block 3 + head: one workgroup (4 waves) per frame.
+// The whole zero-padded block-2 activation ((Hin+2) x 30 x 48 fp32) sits in LDS; pool windows
+// are enumerated row-major, 16 per wave tile (45 windows = 3 tiles at 144 input rows).  The
+// pooled, normalised 5x9x48 tensor goes to LDS, then adaptive average pooling (bins
+// [floor(i*H/4), ceil((i+1)*H/4)) as torch defines them, net.py:88,130), the channel-major
+// flatten (net.py:131), Linear(768,32)+ReLU+BatchNorm1d, Linear(32,3) (net.py:62-68) and the
+// max/argmax of segmentation.py:37 finish the frame.
+// ------------------------------------------------------------------------------------------
+constexpr int kP3W = kW2 + 2;   // 30
+
+__global__ __launch_bounds__(256) void conv3_head_kernel(
+    const float* __restrict__ in, const float* __restrict__ wfrag, const float* __restrict__ post,
+    const float* __restrict__ fc0w, const float* __restrict__ fc0p, const float* __restrict__ fc1w,
+    const float* __restrict__ fc1b, float* __restrict__ logits, float* __restrict__ maxv,
+    int64_t* __restrict__ argmax, int Hin, int Hp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;                                  // [(Hin+2)][30][48]
+    float* pooled = patch + (Hin + 2) * kP3W * kC;        // [Hp][9][48]
+    float* feat = pooled + Hp * kW3 * kC;                 // [768]
+    float* hid = feat + kFeat;                            // [32]
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x;
+    const float* fin = in + (int64_t)frame * Hin * kW2 * kC;
+
+    for (int idx = tid; idx < (Hin + 2) * kP3W * (kC / 4); idx += 256) {
+        int pix = idx / (kC / 4), c4 = idx % (kC / 4);
+        int gy = pix / kP3W - 1, gx = pix % kP3W - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < Hin && gx >= 0 && gx < kW2)
+            v = *reinterpret_cast<const f32x4*>(fin + ((int64_t)gy * kW2 + gx) * kC + 4 * c4);
+        *reinterpret_cast<f32x4*>(patch + pix * kC + 4 * c4) = v;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int q = lane >> 4, ch = lane & 15;
+    const int windows = Hp * kW3;
+    const int wave_tiles = (windows + 15) / 16;
+    for (int wt = wave; wt < wave_tiles; wt += 4) {
+        const int w0 = wt * 16;
+        int base[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int c12 = 4 * j + (i & 3);
+            int W = min(w0 + 4 * (i >> 2) + c12 / 3, windows - 1);
+            int wrow = W / kW3, px = W % kW3;
+            base[j] = ((3 * wrow) * kP3W + 3 * px + c12 % 3) * kC + 4 * kq;
+        }
+        f32x4 acc[3][3][3];
+        // columns of one lane's 12 may straddle pool rows here, so tile (t, j) of lane-row i uses
+        // base[j] for every t and the conv row offset t is applied inside the tile routine
+        conv48_wave_tile(patch, base, kP3W, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int c = nt * 16 + ch;
+            const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
+            float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
+                          window_max<3>(acc, nt)};
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) {
+                int W = w0 + 4 * q + wi;
+                if (W < windows) pooled[W * kC + c] = fmaf(fmaxf(m[wi] + bias, 0.f), sc, sh);
+            }
+        }
+    }
+    __syncthreads();
+
+    // adaptive average pool + flatten: feat[c*16 + bi*4 + bj]
+    for (int o = tid; o < kFeat; o += 256) {
+        int c = o >> 4, bi = (o >> 2) & 3, bj = o & 3;
+        int ys = (bi * Hp) / kPool, ye = ((bi + 1) * Hp + kPool - 1) / kPool;
+        int xs = (bj * kW3) / kPool, xe = ((bj + 1) * kW3 + kPool - 1) / kPool;
+        float sum = 0.f;
+        for (int yy = ys; yy < ye; ++yy)
+            for (int xx = xs; xx < xe; ++xx) sum += pooled[(yy * kW3 + xx) * kC + c];
+        feat[o] = sum / (float)((ye - ys) * (xe - xs));
+    }
+    __syncthreads();
+
+    // Linear(768, 32): 8 lanes per output, 96 inputs each, then a 3-step butterfly
+    {
+        const int o = tid >> 3, part = tid & 7;
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(fc0w + o * kFeat + part * 96);
+        const f32x4* frow = reinterpret_cast<const f32x4*>(feat + part * 96);
+        float sum = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < 24; ++k) {
+            f32x4 w = wrow[k], f = frow[k];
+            sum = fmaf(w[0], f[0], sum); sum = fmaf(w[1], f[1], sum);
+            sum = fmaf(w[2], f[2], sum); sum = fmaf(w[3], f[3], sum);
+        }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        if (part == 0) {
+            float v = fmaxf(sum + fc0p[o], 0.f);
+            hid[o] = fmaf(v, fc0p[kHid + o], fc0p[2 * kHid + o]);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float l[kOut];
+        for (int o = 0; o < kOut; ++o) {
+            float sum = 0.f;
+            for (int k = 0; k < kHid; ++k) sum = fmaf(fc1w[o * kHid + k], hid[k], sum);
+            l[o] = sum + fc1b[o];
+            logits[(int64_t)frame * kOut + o] = l[o];
+        }
+        // torch.max semantics: first maximum wins; a NaN wins over everything (first NaN)
+        float best = l[0];
+        int bi = 0;
+        for (int o = 1; o < kOut; ++o)
+            if (!(best != best) && (l[o] > best || l[o] != l[o])) { best = l[o]; bi = o; }
+        if (maxv) maxv[frame] = best;
+        if (argmax) argmax[frame] = bi;
+    }
+}
+
+int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logits, float* maxv,
+                      int64_t* argmax, hipStream_t s) {
+    const size_t lds = sizeof(float) * ((size_t)(g.h2 + 2) * kP3W * kC + (size_t)g.h3 * kW3 * kC + kFeat + kHid);
+    if (lds > 160 * 1024) {
+        set_error("network input of %d rows needs %zu bytes of LDS in the head kernel (max 163840)", g.h, lds);
+        return CD_EINVAL;
+    }
+    static bool attr_set = false;   // raise the dynamic-LDS limit once per process
+    if (!attr_set) {
+        CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3_head_kernel, dim3((unsigned)n), dim3(256), lds, s, h->act2, h->p.w3,
+                       h->p.post + 6 * kC, h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax,
+                       g.h2, g.h3);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+}  // namespace cd

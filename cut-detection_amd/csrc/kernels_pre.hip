@@ -1,0 +1,164 @@
+// Stand-alone resize+normalise kernel and the synthetic clip generator.
+#include "cd_sample.h"
+
+namespace cd {
+
+// ------------------------------------------------------------------------------------------
+// Resize + normalise: one workgroup per (frame, output row).
+//
+// HBM-bound: the only compulsory traffic is the source rows that are actually sampled
+// (read once, 16 B per lane, into LDS) and the float32 planes written.  The bilinear taps are
+// then picked out of LDS, so the byte-granular, stride-15/22 access pattern never reaches the
+// vector memory pipe.  Output is what reference frameID/data.py:225-228 produces: float32 CHW,
+// RGB order, value/255 (through a table of correctly rounded k/255).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_rows_kernel(
+    const uint8_t* __restrict__ src, SampleArgs a, int64_t frame_stride, int chan_order,
+    float* __restrict__ dst, int nh, int nw, const float* __restrict__ lut, int row_bytes_padded) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t rows[];   // [2][row_bytes_padded]
+    __shared__ float slut[256];
+    const int tid = threadIdx.x;
+    const int y = blockIdx.x % nh;
+    const int f = blockIdx.x / nh;
+    const uint8_t* frame = src + (int64_t)f * frame_stride;
+    slut[tid] = lut[tid];
+
+    int r0, r1;
+    if (a.mode == 2) { r0 = 2 * y; r1 = 2 * y + 1; }
+    else {
+        int sy = a.sy[y];
+        r0 = min(max(sy, 0), a.H0 - 1);
+        r1 = min(max(sy + 1, 0), a.H0 - 1);
+    }
+    const int b0 = a.mode == 0 ? a.by[2 * y] : 0, b1 = a.mode == 0 ? a.by[2 * y + 1] : 0;
+    const bool two_rows = a.mode == 2 || (a.mode == 0 && b1 != 0);
+    const int row_bytes = a.W0 * 3;
+    const int chunks = row_bytes >> 4;
+    {
+        const uint4* g0 = reinterpret_cast<const uint4*>(frame + (int64_t)r0 * a.row_stride);
+        const uint4* g1 = reinterpret_cast<const uint4*>(frame + (int64_t)r1 * a.row_stride);
+        uint4* l0 = reinterpret_cast<uint4*>(rows);
+        uint4* l1 = reinterpret_cast<uint4*>(rows + row_bytes_padded);
+        for (int c = tid; c < chunks; c += 256) {
+            l0[c] = g0[c];
+            if (two_rows) l1[c] = g1[c];
+        }
+        for (int b = (chunks << 4) + tid; b < row_bytes; b += 256) {   // < 16 tail bytes
+            rows[b] = frame[(int64_t)r0 * a.row_stride + b];
+            if (two_rows) rows[row_bytes_padded + b] = frame[(int64_t)r1 * a.row_stride + b];
+        }
+    }
+    __syncthreads();
+    const uint8_t* R0 = rows;
+    const uint8_t* R1 = two_rows ? rows + row_bytes_padded : rows;
+    const int64_t plane = (int64_t)nh * nw;
+    float* out = dst + (int64_t)f * 3 * plane + (int64_t)y * nw;
+    for (int x = tid; x < nw; x += 256) {
+        int v[3];
+        if (a.mode == 1) {
+            int c0 = a.sx[x] * 3;
+            for (int cc = 0; cc < 3; ++cc) v[cc] = R0[c0 + cc];
+        } else if (a.mode == 2) {
+            int c0 = 6 * x;
+            for (int cc = 0; cc < 3; ++cc)
+                v[cc] = (R0[c0 + cc] + R0[c0 + 3 + cc] + R1[c0 + cc] + R1[c0 + 3 + cc] + 2) >> 2;
+        } else {
+            int c0 = a.sx[x], c1 = min(c0 + 1, a.W0 - 1);
+            int a0 = a.ax[2 * x], a1 = a.ax[2 * x + 1];
+            for (int cc = 0; cc < 3; ++cc) {
+                int S0 = R0[c0 * 3 + cc] * a0 + R0[c1 * 3 + cc] * a1;
+                int S1 = R1[c0 * 3 + cc] * a0 + R1[c1 * 3 + cc] * a1;
+                int t = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                v[cc] = min(max(t, 0), 255);
+            }
+        }
+        // plane 0 is R: memory channel 2 when the frame is BGR
+        for (int ci = 0; ci < 3; ++ci) out[ci * plane + x] = slut[v[chan_order == CD_BGR ? 2 - ci : ci]];
+    }
+}
+
+// Fallback for rows that are not 16-byte aligned: taps straight from global memory.
+__global__ __launch_bounds__(256) void preprocess_generic_kernel(
+    const uint8_t* __restrict__ src, SampleArgs a, int64_t frame_stride, int chan_order,
+    float* __restrict__ dst, int nh, int nw, const float* __restrict__ lut) {
+    const int y = blockIdx.x % nh;
+    const int f = blockIdx.x / nh;
+    const uint8_t* frame = src + (int64_t)f * frame_stride;
+    const int64_t plane = (int64_t)nh * nw;
+    float* out = dst + (int64_t)f * 3 * plane + (int64_t)y * nw;
+    for (int x = threadIdx.x; x < nw; x += 256)
+        for (int ci = 0; ci < 3; ++ci)
+            out[ci * plane + x] = lut[sample_u8(frame, y, x, chan_order == CD_BGR ? 2 - ci : ci, a)];
+}
+
+int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                      int64_t frame_stride, int chan_order, float* dst, int nh, int nw, hipStream_t s) {
+    SampleArgs a{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride};
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
+    dim3 grid((unsigned)(n * nh)), block(256);
+    if (aligned) {
+        int padded = (W0 * 3 + 15) & ~15;
+        hipLaunchKernelGGL(preprocess_rows_kernel, grid, block, (size_t)2 * padded, s, src, a, frame_stride,
+                           chan_order, dst, nh, nw, h->p.lut, padded);
+    } else {
+        hipLaunchKernelGGL(preprocess_generic_kernel, grid, block, 0, s, src, a, frame_stride, chan_order, dst,
+                           nh, nw, h->p.lut);
+    }
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic clip generator: integer hash, four bytes per thread.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ dst, int H0, int W0,
+                                                    const uint8_t* __restrict__ classes, uint32_t seed,
+                                                    int64_t first_index, uint32_t frame_elems,
+                                                    int period, int thick) {
+    const int f = blockIdx.y;
+    const uint32_t e0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (e0 >= frame_elems) return;
+    const int cls = classes[f];
+    const uint32_t key = mix32(seed + 0x9E3779B9u * (uint32_t)((first_index + f + 1) & 0xFFFFFFFFll));
+    uint8_t* out = dst + (int64_t)f * frame_elems + e0;
+    uint32_t packed = 0;
+    const uint32_t row_elems = (uint32_t)W0 * 3u;
+    for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t e = e0 + k;
+        if (e >= frame_elems) break;
+        uint32_t r = mix32(key ^ (e * 0x85EBCA6Bu + 0xC2B2AE35u));
+        uint32_t v;
+        if (cls == 0) v = r >> 24;
+        else if (cls == 2) v = r >> 29;
+        else {
+            uint32_t y = e / row_elems, c = e % 3u;
+            uint32_t base = (y % (uint32_t)period) < (uint32_t)thick ? 230u : (c == 1u ? 128u : 26u);
+            v = base + (r >> 29);
+        }
+        packed |= v << (8 * k);
+    }
+    if (e0 + 4 <= frame_elems) *reinterpret_cast<uint32_t*>(out) = packed;
+    else for (uint32_t k = 0; e0 + k < frame_elems; ++k) out[k] = (uint8_t)(packed >> (8 * k));
+}
+
+int launch_synth(uint8_t* dst, int n, int H0, int W0, const uint8_t* classes, uint32_t seed,
+                 int64_t first_index, hipStream_t s) {
+    const uint64_t elems = (uint64_t)H0 * W0 * 3;
+    if (elems >= (1ull << 32) || (elems & 3)) {
+        set_error("cd_synth_frames: frame of %llu bytes unsupported (must be < 4 GiB and a multiple of 4)",
+                  (unsigned long long)elems);
+        return CD_EINVAL;
+    }
+    dim3 grid((unsigned)((elems / 4 + 255) / 256), (unsigned)n), block(256);
+    hipLaunchKernelGGL(synth_kernel, grid, block, 0, s, dst, H0, W0, classes, seed, first_index,
+                       (uint32_t)elems, (12 * W0) / 256, (W0 + 255) / 256);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+}  // namespace cd

@@ -1,0 +1,157 @@
+// Run-length encoding of the per-frame class stream (reference frameID/segmentation.py:39-60).
+//
+// A frame i ends a segment when it is the last frame or cls[i+1] != cls[i].  Three passes:
+//   count    per-block number of segment ends (wave ballots + popcounts)
+//   offsets  one workgroup turns the block counts into exclusive offsets and the total
+//   scatter  every end frame learns its segment index from a wave-level ballot scan
+//            (popcount of the lanes below it) on top of the running block offset
+//   finish   start = previous end + 1, run length, and the per-segment mean of the winning
+//            logit: one wave per segment, fp64 lane partials combined by a butterfly, so the
+//            result does not depend on how the stream was split.
+#include <algorithm>
+
+#include "cd_internal.h"
+
+namespace cd {
+
+constexpr int kRleThreads = 256;
+constexpr int kRleItems = 16;                       // frames per thread
+constexpr int kRleBlock = kRleThreads * kRleItems;  // frames per workgroup
+
+__device__ __forceinline__ bool is_end(const int64_t* __restrict__ cls, int64_t i, int64_t n) {
+    return i < n && (i == n - 1 || cls[i + 1] != cls[i]);
+}
+
+__global__ __launch_bounds__(kRleThreads) void rle_count_kernel(const int64_t* __restrict__ cls, int64_t n,
+                                                               int64_t* __restrict__ block_counts) {
+    __shared__ int wave_counts[kRleThreads / 64];
+    const int64_t b0 = (int64_t)blockIdx.x * kRleBlock;
+    int cnt = 0;
+    for (int it = 0; it < kRleItems; ++it) {
+        unsigned long long m = __ballot(is_end(cls, b0 + it * kRleThreads + threadIdx.x, n));
+        cnt += __popcll(m);
+    }
+    if ((threadIdx.x & 63) == 0) wave_counts[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kRleThreads / 64; ++w) t += wave_counts[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+// in place: counts -> exclusive offsets; *n_seg = total
+__global__ __launch_bounds__(256) void rle_offsets_kernel(int64_t* __restrict__ blocks, int nblocks,
+                                                          int64_t* __restrict__ n_seg) {
+    __shared__ int64_t part[256];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + 255) / 256;
+    const int lo = min(tid * per, nblocks), hi = min(lo + per, nblocks);
+    int64_t s = 0;
+    for (int k = lo; k < hi; ++k) s += blocks[k];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int k = 0; k < 256; ++k) { int64_t v = part[k]; part[k] = run; run += v; }
+        *n_seg = run;
+    }
+    __syncthreads();
+    int64_t run = part[tid];
+    for (int k = lo; k < hi; ++k) { int64_t v = blocks[k]; blocks[k] = run; run += v; }
+}
+
+__global__ __launch_bounds__(kRleThreads) void rle_scatter_kernel(
+    const int64_t* __restrict__ cls, int64_t n, int64_t frame_offset, const int64_t* __restrict__ block_offsets,
+    int64_t* __restrict__ end, int64_t* __restrict__ type, int64_t cap) {
+    __shared__ int wave_counts[kRleThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * kRleBlock;
+    int64_t run = block_offsets[blockIdx.x];
+    for (int it = 0; it < kRleItems; ++it) {
+        const int64_t i = b0 + it * kRleThreads + threadIdx.x;
+        const bool e = is_end(cls, i, n);
+        const unsigned long long m = __ballot(e);
+        if (lane == 0) wave_counts[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < kRleThreads / 64; ++w) {
+            int c = wave_counts[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        if (e) {
+            int64_t k = run + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (k < cap) { end[k] = i + frame_offset; type[k] = cls[i]; }
+        }
+        run += total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void rle_finish_kernel(
+    const float* __restrict__ maxv, int64_t frame_offset, const int64_t* __restrict__ end,
+    int64_t* __restrict__ runlen, int64_t* __restrict__ start, float* __restrict__ mean,
+    double* __restrict__ sum, int64_t cap, const int64_t* __restrict__ n_seg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t S = *n_seg < cap ? *n_seg : cap;
+    for (int64_t k = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < S; k += waves) {
+        const int64_t e = end[k];
+        const int64_t b = k == 0 ? frame_offset : end[k - 1] + 1;
+        double acc = 0.0;
+        for (int64_t i = b - frame_offset + lane; i <= e - frame_offset; i += 64) acc += (double)maxv[i];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            const int64_t len = e - b + 1;
+            start[k] = b;
+            runlen[k] = len;
+            mean[k] = (float)(acc / (double)len);
+            if (sum) sum[k] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void max_argmax_kernel(const float* __restrict__ scores, int64_t n, int ncls,
+                                                         float* __restrict__ maxv, int64_t* __restrict__ argmax) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* r = scores + i * ncls;
+    float best = r[0];
+    int bi = 0;
+    for (int o = 1; o < ncls; ++o) {
+        float v = r[o];
+        if (!(best != best) && (v > best || v != v)) { best = v; bi = o; }
+    }
+    maxv[i] = best;
+    argmax[i] = bi;
+}
+
+int launch_max_argmax(const float* scores, int64_t n, int ncls, float* maxv, int64_t* argmax, hipStream_t s) {
+    hipLaunchKernelGGL(max_argmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, ncls, maxv,
+                       argmax);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+int launch_rle(const cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset,
+               int64_t* end, int64_t* type, int64_t* runlen, int64_t* start, float* mean, double* sum,
+               int64_t cap, int64_t* n_seg, hipStream_t s) {
+    const int64_t nblocks = (n + kRleBlock - 1) / kRleBlock;
+    if (nblocks > h->rle_blocks_cap) {
+        set_error("cd_rle: %lld frames exceed the %lld-frame limit of one call", (long long)n,
+                  (long long)h->rle_blocks_cap * kRleBlock);
+        return CD_EINVAL;
+    }
+    hipLaunchKernelGGL(rle_count_kernel, dim3((unsigned)nblocks), dim3(kRleThreads), 0, s, cls, n, h->rle_blocks);
+    hipLaunchKernelGGL(rle_offsets_kernel, dim3(1), dim3(256), 0, s, h->rle_blocks, (int)nblocks, n_seg);
+    hipLaunchKernelGGL(rle_scatter_kernel, dim3((unsigned)nblocks), dim3(kRleThreads), 0, s, cls, n, frame_offset,
+                       h->rle_blocks, end, type, cap);
+    const unsigned fin_blocks = (unsigned)std::min<int64_t>(1024, (std::min<int64_t>(n, cap) + 3) / 4);
+    hipLaunchKernelGGL(rle_finish_kernel, dim3(fin_blocks), dim3(256), 0, s, maxv, frame_offset, end, runlen,
+                       start, mean, sum, cap, n_seg);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+}  // namespace cd

@@ -1,0 +1,157 @@
+"""Torch-facing wrapper of the native handle: tensors in, tensors out, nothing computed here.
+
+PyTorch supplies device memory and the current HIP stream; every operation is one call into
+libcutdet.so.  Inputs must live on the engine's GPU -- there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+NET_W = 256
+
+
+def output_size(height, width, resize=NET_W):
+    """(new_height, new_width) with the reference's rounding (frameID/data.py:199-202)."""
+    return int(height * (resize / width)), resize
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """One classifier instance on one GPU."""
+
+    def __init__(self, blob, device="cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("cutdet.Engine runs on an MI355X only; got device %r (no CPU fallback)" % (device,))
+        if not torch.cuda.is_available():
+            raise RuntimeError("cutdet.Engine: no GPU visible (torch.cuda.is_available() is False)")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        self._blob = bytes(blob)
+        self._h = C.c_void_p(0)
+        check(lib.cd_create(C.byref(self._h), self._blob, len(self._blob), index, _lib.CD_F32))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.cd_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_dev(self, t, name, dtype):
+        if not torch.is_tensor(t) or t.device != self.device:
+            raise RuntimeError(f"{name} must be a tensor on {self.device} (got {getattr(t, 'device', type(t))})")
+        if t.dtype != dtype:
+            raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+
+    def _frame_layout(self, frames):
+        self._check_dev(frames, "frames", torch.uint8)
+        if frames.dim() != 4 or frames.shape[3] != 3 or frames.stride(3) != 1 or frames.stride(2) != 3:
+            raise ValueError("frames must be u8 [n, H0, W0, 3] with interleaved pixels")
+        n, H0, W0, _ = frames.shape
+        return n, H0, W0, frames.stride(1), frames.stride(0) if n > 1 else max(frames.stride(0), frames.stride(1) * H0)
+
+    def reserve(self, max_frames, net_h=144):
+        check(lib.cd_reserve(self._h, int(max_frames), int(net_h)))
+
+    # ------------------------------------------------------------------ operations
+    def preprocess(self, frames, chan_order=_lib.CD_BGR, resize=NET_W, out=None):
+        """u8 [n,H0,W0,3] -> f32 [n,3,h,resize] RGB/255 (reference frameID/data.py:218-228)."""
+        n, H0, W0, rs, fs = self._frame_layout(frames)
+        nh, nw = output_size(H0, W0, resize)
+        if out is None:
+            out = torch.empty((n, 3, nh, nw), dtype=torch.float32, device=self.device)
+        check(lib.cd_preprocess(self._h, _ptr(frames), n, H0, W0, rs, fs, chan_order, _ptr(out), nh, nw,
+                                self._stream()))
+        return out
+
+    def _outputs(self, n, want_max):
+        logits = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        if not want_max:
+            return logits, None, None
+        return (logits, torch.empty((n,), dtype=torch.float32, device=self.device),
+                torch.empty((n,), dtype=torch.int64, device=self.device))
+
+    def forward(self, x, want_max=False):
+        """f32 [n,3,h,256] -> logits [n,3] (and max, argmax)."""
+        self._check_dev(x, "x", torch.float32)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"x must be [n,3,h,{NET_W}], got {tuple(x.shape)}")
+        x = x.contiguous()
+        n, _, nh, nw = x.shape
+        logits, mx, am = self._outputs(n, want_max)
+        if n:
+            check(lib.cd_forward(self._h, _ptr(x), n, nh, nw, _ptr(logits), _ptr(mx), _ptr(am), self._stream()))
+        return (logits, mx, am) if want_max else logits
+
+    def forward_u8(self, frames, chan_order=_lib.CD_BGR, resize=NET_W, want_max=True):
+        """u8 [n,H0,W0,3] -> logits (and max, argmax) with the resize fused into the first layer."""
+        n, H0, W0, rs, fs = self._frame_layout(frames)
+        nh, nw = output_size(H0, W0, resize)
+        logits, mx, am = self._outputs(n, want_max)
+        check(lib.cd_forward_u8(self._h, _ptr(frames), n, H0, W0, rs, fs, chan_order, nh, nw, _ptr(logits),
+                                _ptr(mx), _ptr(am), self._stream()))
+        return (logits, mx, am) if want_max else logits
+
+    def max_argmax(self, scores):
+        """f32 [n,k] -> (max f32 [n], argmax i64 [n]); torch.max(scores, 1) semantics."""
+        self._check_dev(scores, "scores", torch.float32)
+        if scores.dim() != 2 or scores.shape[1] < 1:
+            raise ValueError("scores must be [n, k]")
+        scores = scores.contiguous()
+        n, k = scores.shape
+        mx = torch.empty((n,), dtype=torch.float32, device=self.device)
+        am = torch.empty((n,), dtype=torch.int64, device=self.device)
+        if n:
+            check(lib.cd_max_argmax(self._h, _ptr(scores), n, k, _ptr(mx), _ptr(am), self._stream()))
+        return mx, am
+
+    def rle(self, cls, maxv, frame_offset=0, cap=None):
+        """Class stream -> dict of device tensors (end_frames, frame_types, run_lengths, start_frames,
+        score_means, score_sums) trimmed to the number of segments.  Synchronises to read the count."""
+        self._check_dev(cls, "cls", torch.int64)
+        self._check_dev(maxv, "maxv", torch.float32)
+        cls, maxv = cls.contiguous(), maxv.contiguous()
+        n = cls.shape[0]
+        if n == 0:
+            raise IndexError("no frames to segment")
+        cap = n if cap is None else int(cap)
+        i64 = dict(dtype=torch.int64, device=self.device)
+        end, typ, rl, st = (torch.empty((cap,), **i64) for _ in range(4))
+        mean = torch.empty((cap,), dtype=torch.float32, device=self.device)
+        ssum = torch.empty((cap,), dtype=torch.float64, device=self.device)
+        nseg = torch.zeros((1,), **i64)
+        check(lib.cd_rle(self._h, _ptr(cls), _ptr(maxv), n, int(frame_offset), _ptr(end), _ptr(typ), _ptr(rl),
+                         _ptr(st), _ptr(mean), _ptr(ssum), cap, _ptr(nseg), self._stream()))
+        s = int(nseg.item())
+        if s > cap:
+            raise _lib.CutdetError(_lib.CD_ECAP, f"{s} segments exceed capacity {cap}")
+        return {"end_frames": end[:s], "frame_types": typ[:s], "run_lengths": rl[:s], "start_frames": st[:s],
+                "score_means": mean[:s], "score_sums": ssum[:s]}
+
+    def synth_frames(self, classes, H0, W0, seed=1234, first_index=0, out=None):
+        """Deterministic synthetic clip: u8 [n,H0,W0,3] for per-frame class ids (device u8 tensor)."""
+        self._check_dev(classes, "classes", torch.uint8)
+        n = classes.shape[0]
+        if out is None:
+            out = torch.empty((n, H0, W0, 3), dtype=torch.uint8, device=self.device)
+        step = 32768
+        for a in range(0, n, step):
+            b = min(n, a + step)
+            check(lib.cd_synth_frames(self._h, _ptr(out[a:b]), b - a, H0, W0, _ptr(classes[a:b].contiguous()),
+                                      int(seed) & 0xFFFFFFFF, int(first_index) + a, self._stream()))
+        return out

@@ -1,0 +1,77 @@
+"""A minimal container for already-decoded video: a 64-byte header followed by u8 frames.
+
+Video decoding is outside this package (the reference delegates it to OpenCV,
+frameID/data.py:19-24,213); boxes without OpenCV can still feed the pipeline from this format.
+
+    offset  0  8 bytes  magic b"CDRAWVID"
+            8  u32 x 6  version (1), width, height, frame count, fps, channel order (0 BGR, 1 RGB)
+           32  zero padding to 64 bytes
+           64  frames, each height*width*3 bytes, rows top to bottom, pixels interleaved
+"""
+import struct
+
+import numpy as np
+
+MAGIC = b"CDRAWVID"
+HEADER_BYTES = 64
+
+# the cv2.CAP_PROP_* ids the reference queries (frameID/data.py:20-24)
+CAP_PROP_FRAME_WIDTH, CAP_PROP_FRAME_HEIGHT, CAP_PROP_FPS, CAP_PROP_FRAME_COUNT = 3, 4, 5, 7
+
+
+def write_raw_video(path, frames, fps=30, chan_order=0):
+    """frames: u8 array [n, H, W, 3] (or an iterable of [H, W, 3] arrays)."""
+    frames = np.asarray(frames, dtype=np.uint8)
+    if frames.ndim != 4 or frames.shape[3] != 3:
+        raise ValueError("frames must be [n, H, W, 3] uint8")
+    n, h, w, _ = frames.shape
+    with open(path, "wb") as f:
+        f.write(MAGIC + struct.pack("<6I", 1, w, h, n, int(fps), int(chan_order)) + b"\0" * (HEADER_BYTES - 32))
+        f.write(np.ascontiguousarray(frames).tobytes())
+
+
+def is_raw_video(path):
+    try:
+        with open(path, "rb") as f:
+            return f.read(8) == MAGIC
+    except OSError:
+        return False
+
+
+class RawVideoCapture:
+    """The slice of cv2.VideoCapture's interface the pipeline uses, over the raw container."""
+
+    def __init__(self, path):
+        with open(path, "rb") as f:
+            head = f.read(HEADER_BYTES)
+        if len(head) < HEADER_BYTES or head[:8] != MAGIC:
+            raise ValueError(f"{path} is not a CDRAWVID file")
+        ver, self.width, self.height, self.length, self.fps, self.chan_order = struct.unpack("<6I", head[8:32])
+        if ver != 1:
+            raise ValueError(f"{path}: unsupported CDRAWVID version {ver}")
+        self._frames = np.memmap(path, dtype=np.uint8, mode="r", offset=HEADER_BYTES,
+                                 shape=(self.length, self.height, self.width, 3))
+        self._pos = 0
+
+    def isOpened(self):
+        return True
+
+    def get(self, prop):
+        return float({CAP_PROP_FRAME_WIDTH: self.width, CAP_PROP_FRAME_HEIGHT: self.height,
+                      CAP_PROP_FPS: self.fps, CAP_PROP_FRAME_COUNT: self.length}.get(prop, 0))
+
+    def read(self):
+        if self._pos >= self.length:
+            return False, None
+        frame = np.array(self._frames[self._pos])
+        self._pos += 1
+        return True, frame
+
+    def read_batch(self, n):
+        """Up to n consecutive frames as one [k, H, W, 3] array (k = 0 at the end)."""
+        a, b = self._pos, min(self.length, self._pos + n)
+        self._pos = b
+        return np.array(self._frames[a:b])
+
+    def release(self):
+        self._frames = None

@@ -1,0 +1,107 @@
+"""Video input with the reference's names (`open_video`, `VideoDataset`), preprocessed on the GPU.
+
+Mirrors reference frameID/data.py:13-31 and :184-234.  Decoding stays outside: a capture
+object (OpenCV's when cv2 is importable, else the raw container of cutdet.rawvideo) hands over
+u8 BGR frames; resize + float conversion + channel flip + /255 (reference :218-228) happen in
+one HIP kernel on batches of frames, and the dataset yields the resulting [3, h, w] float32
+tensors -- on the GPU, so the driver's `batch.to(device)` is free.
+
+The training-only datasets of the reference are not part of this package; the class-name table
+they define (reference :116) is kept because the segmentation output needs it.
+"""
+import torch
+from torch.utils.data import IterableDataset
+
+from cutdet import api, rawvideo
+
+
+class SupervisedFrameDataset:
+    """Holder of the label table only (the reference's training dataset is out of scope)."""
+
+    lab_enum = {"a22": 0, "ez": 1, "b": 2}
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("training datasets are not part of the inference package")
+
+
+def open_video(video_path):
+    """Open a video; returns `(capture, {"fps", "length", "width", "height"})` with int values."""
+    if rawvideo.is_raw_video(video_path):
+        cap = rawvideo.RawVideoCapture(video_path)
+        ids = (rawvideo.CAP_PROP_FPS, rawvideo.CAP_PROP_FRAME_COUNT, rawvideo.CAP_PROP_FRAME_WIDTH,
+               rawvideo.CAP_PROP_FRAME_HEIGHT)
+    else:
+        try:
+            import cv2
+        except ImportError as e:
+            raise ImportError(f"{video_path} is not a CDRAWVID file and OpenCV (cv2) is not installed "
+                              "to decode it") from e
+        cap = cv2.VideoCapture(video_path)
+        ids = (cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_COUNT, cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT)
+    fps, length, width, height = (int(cap.get(i)) for i in ids)
+    return cap, {"fps": fps, "length": length, "width": width, "height": height}
+
+
+class VideoDataset(IterableDataset):
+    """Iterates the frames of a video as float32 [3, new_height, new_width] RGB tensors in [0,1]."""
+
+    def __init__(self, file_path, resize=None, device="cuda:0", read_ahead=64):
+        super().__init__()
+        self.cap, self.video_info = open_video(file_path)
+        self.device = torch.device(device)
+        self.read_ahead = int(read_ahead)
+        self.chan_order = getattr(self.cap, "chan_order", 0)
+        if resize is not None:
+            self.new_width = resize
+            self.new_height = int(self.video_info["height"] * (self.new_width / self.video_info["width"]))
+        else:
+            self.new_width = None
+            self.new_height = None
+        self._ready = None   # preprocessed frames of the current read-ahead batch
+        self._next = 0
+
+    # --- decoded frames ------------------------------------------------------------------
+    def read_u8_batch(self, n):
+        """Next up-to-n decoded frames as a u8 [k,H,W,3] tensor on the GPU (k = 0 at the end)."""
+        if hasattr(self.cap, "read_batch"):
+            arr = self.cap.read_batch(n)
+            host = torch.from_numpy(arr)
+        else:
+            got = []
+            while len(got) < n:
+                ret, frame = self.cap.read()
+                if not ret:
+                    break
+                got.append(torch.from_numpy(frame))
+            host = torch.stack(got) if got else torch.empty((0, self.video_info["height"],
+                                                             self.video_info["width"], 3), dtype=torch.uint8)
+        return host.to(self.device, non_blocking=False)
+
+    def frame_batches(self, batch_size):
+        """Yields u8 GPU batches for the fused classify path (no float frames materialised)."""
+        while True:
+            b = self.read_u8_batch(batch_size)
+            if b.shape[0] == 0:
+                return
+            yield b
+
+    # --- the reference's iteration protocol ---------------------------------------------------
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._ready is None or self._next >= self._ready.shape[0]:
+            raw = self.read_u8_batch(self.read_ahead)
+            if raw.shape[0] == 0:
+                raise StopIteration
+            eng = api.default_engine(self.device)
+            resize = self.new_width if self.new_width is not None else self.video_info["width"]
+            self._ready = eng.preprocess(raw, chan_order=self.chan_order, resize=resize)
+            self._next = 0
+        frame = self._ready[self._next]
+        self._next += 1
+        return frame
+
+    def __len__(self):
+        """Note iterables don't necessarily have len, but this one does."""
+        return self.video_info["length"]

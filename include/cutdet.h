@@ -1,0 +1,111 @@
+/*
+ * cutdet.h -- C ABI of libcutdet.so, the MI355X (gfx950) classify+segment hot path.
+ *
+ * The reference (play4honor/Cut-Detection) is pure Python and has no FFI of its own; each entry
+ * point below names the Python call it stands in for.  Bindings use plain pointers and sizes
+ * (ctypes: cut-detection_amd/cutdet/_lib.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative CD_E* code on failure; the message for
+ *     the calling thread's last failure is cd_last_error().  Nothing throws across the ABI.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is queued
+ *     on it; no call synchronises the device.
+ *   - pointers marked "device" must be device memory on the handle's GPU.  Frames, activations
+ *     and results are caller-owned; the handle owns the packed weights and an activation
+ *     workspace that grows only inside cd_reserve()/the first call that needs more.
+ *   - a handle is bound to one device and is not thread-safe; distinct handles are independent.
+ */
+#ifndef CUTDET_H
+#define CUTDET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cd_handle cd_handle;
+
+enum {
+    CD_OK = 0,
+    CD_EINVAL = -1,   /* bad argument / unsupported shape */
+    CD_EHIP = -2,     /* a HIP runtime call failed */
+    CD_ECAP = -3,     /* caller-provided capacity too small */
+    CD_ENOMEM = -4
+};
+
+enum { CD_F32 = 0 };                     /* arithmetic type of the forward pass */
+enum { CD_BGR = 0, CD_RGB = 1 };         /* channel order of u8 frames in memory */
+
+int cd_version(void);
+const char* cd_last_error(void);
+
+/* Builds the classifier from a weight blob (format: cut-detection_amd/cutdet/weights.py).
+ * Replaces frameID/net.py:193-217 load_and_glue_nets() + segment_video.py:33-34 eval()/to(device). */
+int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int device, int dtype);
+void cd_destroy(cd_handle* h);
+
+/* Sizes the activation workspace for batches of up to max_frames frames of network input
+ * height net_h (width is always 256).  Optional: the forward calls grow it on demand. */
+int cd_reserve(cd_handle* h, int max_frames, int net_h);
+
+/* Resize + normalise n decoded frames.
+ * Replaces frameID/data.py:218-228 (cv2.resize INTER_LINEAR to w x h, float32, HWC->CHW,
+ * BGR->RGB, /255).  src: device u8 [n][H0][row_stride bytes], pixels interleaved 3 bytes;
+ * frame_stride = bytes between frames.  dst: device f32 [n][3][h][w], RGB planes in [0,1]. */
+int cd_preprocess(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
+                  int64_t row_stride, int64_t frame_stride, int chan_order,
+                  float* dst, int net_h, int net_w, void* stream);
+
+/* prod_net forward on preprocessed frames.
+ * Replaces net(batch) at segment_video.py:45 (frameID/net.py:33-40,62-68,122-133) and, through
+ * maxv/argmax, torch.max(scores, 1) at frameID/segmentation.py:37.
+ * x: device f32 [n][3][net_h][256].  logits: device f32 [n][3].  maxv (f32 [n]) and
+ * argmax (i64 [n]) may each be NULL.  Ties resolve to the lowest class index. */
+int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w,
+               float* logits, float* maxv, int64_t* argmax, void* stream);
+
+/* cd_preprocess + cd_forward fused: the resized frame never reaches HBM.
+ * Replaces the data.py:218-228 -> segment_video.py:44-45 chain for one batch. */
+int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
+                  int64_t row_stride, int64_t frame_stride, int chan_order,
+                  int net_h, int net_w,
+                  float* logits, float* maxv, int64_t* argmax, void* stream);
+
+/* Per-row maximum and its index over scores (device f32 [n][n_classes], row-major).
+ * Replaces torch.max(scores, dim=1) at frameID/segmentation.py:37 for callers that hold raw
+ * logits.  First maximum wins; a NaN wins over any number (the first NaN), as in torch. */
+int cd_max_argmax(cd_handle* h, const float* scores, int64_t n, int n_classes,
+                  float* maxv, int64_t* argmax, void* stream);
+
+/* Run-length encodes a per-frame class stream into segments.
+ * Replaces frameID/segmentation.py:39-60 (Segmentation.__init__ after the max).
+ * cls (i64 [n]) and maxv (f32 [n]) are device arrays.  Outputs are device arrays of capacity
+ * `cap` rows: end, type, runlen, start (i64), mean (f32: per-segment mean of maxv), sum (f64,
+ * may be NULL: per-segment sum of maxv).  frame_offset is added to every start/end.
+ * n_seg: device i64[1], receives the number of segments found (even when it exceeds cap, in
+ * which case only the first cap rows are written and the caller must treat it as CD_ECAP). */
+int cd_rle(cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset,
+           int64_t* end, int64_t* type, int64_t* runlen, int64_t* start, float* mean, double* sum,
+           int64_t cap, int64_t* n_seg, void* stream);
+
+/* Fills dst (device u8 [n][H0][W0][3]) with the deterministic synthetic clip used by the
+ * benchmark and the tests: frame i has class classes[i] (device u8 [n]: 0 noise, 1 striped
+ * green, 2 near-black) and global index first_index + i.  No counterpart in the reference. */
+int cd_synth_frames(cd_handle* h, uint8_t* dst, int n, int H0, int W0,
+                    const uint8_t* classes, uint32_t seed, int64_t first_index, void* stream);
+
+/* Host-side orphan gluing + adjacent merge on a segment table in host memory, in place.
+ * Replaces frameID/segmentation.py:91-166 glue_orphans() and :168-183
+ * combine_adjacent_segments().  Arrays hold *n_seg rows on entry; on return *n_seg is the new
+ * row count.  steps: bit 0 = glue orphans, bit 1 = merge adjacent.
+ * Returns CD_EINVAL with message "index out of bounds" where the reference raises IndexError
+ * (the table collapsed to a single segment that is still an orphan). */
+int cd_glue_segments(int64_t* end, int64_t* type, int64_t* runlen, int64_t* start, float* mean,
+                     int64_t* n_seg, int64_t real_threshold, int64_t blank_threshold, int steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTDET_H */
