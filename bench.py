@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the classify+segment hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (per GPU): a 10 000-frame synthetic 1280x720 clip resident in HBM as u8, classified in
+batches of 256 frames (fp32) and segmented.  One STEP = one batch through the fused
+resize+prod_net forward; whenever a step finishes the clip (every 40th step) and once more at
+the end of the timed region, the per-frame streams are (all-gathered and) run-length encoded on
+the GPU, repaired and merged on the host and rendered to CSV bytes -- all inside the timed
+region.  With N > 1 every rank owns its own 10 000-frame range (weak scaling); the only
+exchange is the all-gather of the (class, max) streams at clip end.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "cut-detection_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CLIP_FRAMES = 10_000
+BATCH = 256
+H0, W0 = 720, 1280
+NET_H = 144
+SEED = 1234
+
+# algorithmic work per frame, independent of the source resolution (2 flops per MAC):
+#   block 1: 144*256 px * 48 ch * 27 ; block 2: 48*85 * 48 * 432 ; block 3: 16*28 * 48 * 432 ; FC 768*32 + 32*3
+FLOPS_CONV1 = 2 * 144 * 256 * 48 * 27
+FLOPS_CONV2 = 2 * 48 * 85 * 48 * 432
+FLOPS_CONV3 = 2 * 16 * 28 * 48 * 432
+FLOPS_FC = 2 * (768 * 32 + 32 * 3)
+FLOPS_FRAME = FLOPS_CONV1 + FLOPS_CONV2 + FLOPS_CONV3 + FLOPS_FC          # 283 386 048
+BYTES_FRAME_720P = 144 * 1280 * 3 + 12                                      # sampled source rows + logits
+PEAK_F32_MFMA_TFLOPS = 157.3                                                # dense fp32 matrix peak, MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--clip-frames", type=int, default=CLIP_FRAMES)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batches", type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_u8_cpu, n_warm_batches, n_timed_batches):
+    """The CPU oracle (port of the reference's CPU path) on a bounded sample of the same clip:
+    numpy resize + /255, the traced torch prod_net at batch 128 (segment_video.py:104 default),
+    then segmentation.  Returns the dict reported as `cpu_baseline`."""
+    from oracle import net as onet, preprocess, segmentation
+    bs = 128
+    w = onet.load_blob()
+    traced = onet.traced_cpu_net(w)
+    frames = frames_u8_cpu.numpy()
+
+    def run(a, b):
+        x = torch.from_numpy(preprocess.preprocess_batch(frames[a:b]))
+        with torch.no_grad():
+            return traced(x)
+
+    for i in range(n_warm_batches):
+        run(i * bs, (i + 1) * bs)
+    t0 = time.perf_counter()
+    outs, t_net = [], 0.0
+    a0 = n_warm_batches * bs
+    for i in range(n_timed_batches):
+        a = a0 + i * bs
+        x = torch.from_numpy(preprocess.preprocess_batch(frames[a:a + bs]))
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            outs.append(traced(x))
+        t_net += time.perf_counter() - t1
+    scores = torch.cat(outs).numpy()
+    try:
+        segmentation.segment_clip(scores)
+    except IndexError:
+        pass
+    dt = time.perf_counter() - t0
+    n = n_timed_batches * bs
+    return {
+        "value": round(n / dt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        "net_only_frames_per_s": round(n / t_net, 2), "host_cpus": os.cpu_count(),
+        "sample": f"{n} frames (batches of {bs}) of the same 1280x720 clip after {n_warm_batches} warm-up "
+                  f"batches: numpy point-sample resize + /255, torch.jit-traced fp32 prod_net, segmentation",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cutdet import api, synth as csynth
+    from cutdet.pipeline import ClipClassifier
+
+    eng = api.default_engine(dev)
+    n_clip, bs = args.clip_frames, args.batch
+    # this rank's contiguous frame range of the (world * n_clip)-frame game
+    runs = csynth.run_table(world * n_clip, SEED)
+    classes_all = csynth.classes_from_runs(runs)
+    first = rank * n_clip
+    classes = torch.tensor(classes_all[first:first + n_clip], dtype=torch.uint8, device=dev)
+    frames = eng.synth_frames(classes, H0, W0, SEED, first_index=first)      # [n_clip,720,1280,3] u8 in HBM
+    eng.reserve(bs, NET_H)
+    clip = ClipClassifier(eng, n_clip)
+    batches = [(a, min(n_clip, a + bs)) for a in range(0, n_clip, bs)]
+    group = dist.group.WORLD if world > 1 else None
+    torch.cuda.synchronize()
+
+    def step(i):
+        a, b = batches[i % len(batches)]
+        clip.classify(frames[a:b], a)
+        return b - a
+
+    def clip_tail(n_local):
+        # every rank takes part in the gather; rank 0's result is the job's output
+        return clip.segment(n_local, 100, 10, group=group)
+
+    # ---- warm-up (untimed): W steps + one segmentation so RCCL and every kernel are initialised
+    for i in range(args.warmup):
+        step(i)
+    if args.warmup > 0:
+        try:
+            clip_tail(batches[min(args.warmup, len(batches)) - 1][1])
+        except IndexError:   # a warm-up prefix too short to hold one full-length shot
+            pass
+    torch.cuda.synchronize()
+
+    # ---- timed region
+    eng.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames_done, result, pending = 0, None, 0
+    for i in range(args.steps):
+        frames_done += step(i)
+        pending = batches[i % len(batches)][1]
+        if (i + 1) % len(batches) == 0:
+            result = clip_tail(n_clip)
+            pending = 0
+    if pending:
+        result = clip_tail(pending)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing = eng.timing_read()
+    eng.timing_enable(False)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    total_frames = frames_done * world
+
+    if rank == 0:
+        # sanity: the segmentation of the synthetic clip must recover its long shots
+        merged = result["merged"]
+        n_launch, ms = timing["conv2"]
+        frames_per_launch = frames_done / max(1, n_launch)
+        conv2_ms = ms / max(1, n_launch)
+        achieved = FLOPS_CONV2 * frames_per_launch / (conv2_ms * 1e-3) / 1e12 if n_launch else 0.0
+        stages = {k: {"launches": v[0], "ms_total": round(v[1], 3)} for k, v in timing.items() if v[0]}
+        fps = total_frames / dt_max
+        out = {
+            "metric": "frames/sec classified+segmented, 1280x720 RGB",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{n_clip} synthetic 1280x720 u8 frames per GPU resident in HBM, batch={bs}, "
+                                   "fp32 prod_net, fused resize+classify, GPU run-length encode, host glue/merge, CSV",
+                       "frames_per_gpu_timed": frames_done, "segments_out": int(len(merged["start_frames"])),
+                       "stitch": "all-gather of (class,max) streams over RCCL" if world > 1 else "none"},
+            "roofline": {
+                "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None, "launch_ms": round(conv2_ms, 4), "flops_per_frame": FLOPS_CONV2,
+                "frames_per_launch": round(frames_per_launch, 2),
+                "whole_net_tflops": round(FLOPS_FRAME * fps / world / 1e12, 2),
+                "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "hbm_compulsory_GBps": round(BYTES_FRAME_720P * fps / world / 1e9, 2),
+                "hbm_frac_of_peak": round(BYTES_FRAME_720P * fps / world / 1e9 / PEAK_HBM_GBS, 5),
+            },
+            "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nb = args.cpu_sample_batches
+            sample = frames[: (2 + nb) * 128].cpu()
+            out["cpu_baseline"] = cpu_baseline(sample, 2, nb)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

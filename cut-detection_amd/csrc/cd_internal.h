@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdarg.h>
 
+#include <vector>
+
 #include "../../include/cutdet.h"
 
 namespace cd {
@@ -63,6 +65,10 @@ struct cd_handle {
     size_t act1_bytes, act2_bytes;
     int64_t* rle_blocks;    // workspace of cd_rle: per-block boundary counts / offsets
     int rle_blocks_cap;
+    // optional per-stage timing: HIP event pairs recorded around each stage's launches
+    bool timing;
+    std::vector<hipEvent_t> ev_start[CD_STAGE_COUNT], ev_stop[CD_STAGE_COUNT];
+    size_t ev_used[CD_STAGE_COUNT];
 };
 
 namespace cd {

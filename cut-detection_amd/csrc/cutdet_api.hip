@@ -193,6 +193,31 @@ int check_net_shape(int n, int net_h, int net_w, Geometry* g) {
     return CD_OK;
 }
 
+// Brackets the launches issued during its lifetime with an event pair when timing is on.
+struct StageTimer {
+    cd_handle* h;
+    int stage;
+    hipStream_t s;
+    bool live = false;
+    StageTimer(cd_handle* h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_) {
+        if (!h->timing) return;
+        size_t k = h->ev_used[stage];
+        if (k == h->ev_start[stage].size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess) return;
+            if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+            h->ev_start[stage].push_back(a);
+            h->ev_stop[stage].push_back(b);
+        }
+        live = hipEventRecord(h->ev_start[stage][k], s) == hipSuccess;
+    }
+    ~StageTimer() {
+        if (!live) return;
+        size_t k = h->ev_used[stage];
+        if (hipEventRecord(h->ev_stop[stage][k], s) == hipSuccess) h->ev_used[stage] = k + 1;
+    }
+};
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -240,7 +265,6 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     std::memcpy(f.data(), b + kHeader, (size_t)want_floats * 4);
     cd_handle* h = new (std::nothrow) cd_handle();
     if (!h) { set_error("cd_create: out of host memory"); return CD_ENOMEM; }
-    std::memset(h, 0, sizeof *h);
     h->device = device;
     h->dtype = dtype;
     ParamOffsets off;
@@ -277,6 +301,10 @@ void cd_destroy(cd_handle* h) {
     if (h->act1) (void)hipFree(h->act1);
     if (h->act2) (void)hipFree(h->act2);
     if (h->rle_blocks) (void)hipFree(h->rle_blocks);
+    for (int st = 0; st < CD_STAGE_COUNT; ++st) {
+        for (hipEvent_t e : h->ev_start[st]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->ev_stop[st]) (void)hipEventDestroy(e);
+    }
     delete h;
 }
 
@@ -309,6 +337,7 @@ int cd_preprocess(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;
+    StageTimer t(h, CD_STAGE_PREPROCESS, s);
     return launch_preprocess(h, src, n, H0, W0, row_stride, frame_stride, chan_order, dst, net_h, net_w, s);
 }
 
@@ -321,8 +350,9 @@ int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w, float*
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = ensure_workspace(h, n, g, s))) return rc;
-    if ((rc = launch_conv1_f32(h, x, n, g, s))) return rc;
-    if ((rc = launch_conv2(h, n, g, s))) return rc;
+    { StageTimer t(h, CD_STAGE_CONV1, s); if ((rc = launch_conv1_f32(h, x, n, g, s))) return rc; }
+    { StageTimer t(h, CD_STAGE_CONV2, s); if ((rc = launch_conv2(h, n, g, s))) return rc; }
+    StageTimer t(h, CD_STAGE_CONV3_HEAD, s);
     return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
 }
 
@@ -338,8 +368,12 @@ int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;
     if ((rc = ensure_workspace(h, n, g, s))) return rc;
-    if ((rc = launch_conv1_u8(h, src, n, H0, W0, row_stride, frame_stride, chan_order, g, s))) return rc;
-    if ((rc = launch_conv2(h, n, g, s))) return rc;
+    {
+        StageTimer t(h, CD_STAGE_CONV1, s);
+        if ((rc = launch_conv1_u8(h, src, n, H0, W0, row_stride, frame_stride, chan_order, g, s))) return rc;
+    }
+    { StageTimer t(h, CD_STAGE_CONV2, s); if ((rc = launch_conv2(h, n, g, s))) return rc; }
+    StageTimer t(h, CD_STAGE_CONV3_HEAD, s);
     return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
 }
 
@@ -353,6 +387,7 @@ int cd_rle(cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64
     if (n < 1) { set_error("cd_rle: no frames (index out of bounds)"); return CD_EINVAL; }
     if (cap < 1) { set_error("cd_rle: capacity %lld", (long long)cap); return CD_ECAP; }
     DeviceGuard guard(h->device);
+    StageTimer t(h, CD_STAGE_RLE, static_cast<hipStream_t>(stream));
     return launch_rle(h, cls, maxv, n, frame_offset, end, type, runlen, start, mean, sum, cap, n_seg,
                       static_cast<hipStream_t>(stream));
 }
@@ -365,6 +400,32 @@ int cd_max_argmax(cd_handle* h, const float* scores, int64_t n, int n_classes, f
     }
     DeviceGuard guard(h->device);
     return launch_max_argmax(scores, n, n_classes, maxv, argmax, static_cast<hipStream_t>(stream));
+}
+
+int cd_timing_enable(cd_handle* h, int on) {
+    if (!h) { set_error("cd_timing_enable: null handle"); return CD_EINVAL; }
+    h->timing = on != 0;
+    if (!on) for (int st = 0; st < CD_STAGE_COUNT; ++st) h->ev_used[st] = 0;
+    return CD_OK;
+}
+
+int cd_timing_read(cd_handle* h, int stage, int64_t* launches, double* total_ms) {
+    if (!h || !launches || !total_ms || stage < 0 || stage >= CD_STAGE_COUNT) {
+        set_error("cd_timing_read: bad argument");
+        return CD_EINVAL;
+    }
+    DeviceGuard guard(h->device);
+    double ms = 0.0;
+    for (size_t k = 0; k < h->ev_used[stage]; ++k) {
+        CD_HIP(hipEventSynchronize(h->ev_stop[stage][k]));
+        float one = 0.f;
+        CD_HIP(hipEventElapsedTime(&one, h->ev_start[stage][k], h->ev_stop[stage][k]));
+        ms += one;
+    }
+    *launches = (int64_t)h->ev_used[stage];
+    *total_ms = ms;
+    h->ev_used[stage] = 0;
+    return CD_OK;
 }
 
 int cd_synth_frames(cd_handle* h, uint8_t* dst, int n, int H0, int W0, const uint8_t* classes, uint32_t seed,

@@ -19,6 +19,7 @@ lib = C.CDLL(LIB_PATH)
 CD_OK, CD_EINVAL, CD_EHIP, CD_ECAP, CD_ENOMEM = 0, -1, -2, -3, -4
 CD_F32 = 0
 CD_BGR, CD_RGB = 0, 1
+STAGES = ("preprocess", "conv1", "conv2", "conv3_head", "rle")
 
 _h = C.c_void_p
 _p = C.c_void_p
@@ -37,6 +38,8 @@ SIGNATURES = {
     "cd_max_argmax": (C.c_int, [_h, _p, _l, _i, _p, _p, _p]),
     "cd_rle": (C.c_int, [_h, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
     "cd_synth_frames": (C.c_int, [_h, _p, _i, _i, _i, _p, C.c_uint32, _l, _p]),
+    "cd_timing_enable": (C.c_int, [_h, _i]),
+    "cd_timing_read": (C.c_int, [_h, _i, C.POINTER(_l), C.POINTER(C.c_double)]),
     "cd_glue_segments": (C.c_int, [_p, _p, _p, _p, _p, C.POINTER(_l), _l, _l, _i]),
 }
 

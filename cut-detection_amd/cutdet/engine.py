@@ -79,7 +79,16 @@ class Engine:
                                 self._stream()))
         return out
 
-    def _outputs(self, n, want_max):
+    def _outputs(self, n, want_max, out=None):
+        if out is not None:
+            logits, mx, am = out
+            self._check_dev(logits, "out[0]", torch.float32)
+            self._check_dev(mx, "out[1]", torch.float32)
+            self._check_dev(am, "out[2]", torch.int64)
+            if tuple(logits.shape) != (n, 3) or tuple(mx.shape) != (n,) or tuple(am.shape) != (n,) or not (
+                    logits.is_contiguous() and mx.is_contiguous() and am.is_contiguous()):
+                raise ValueError("out must be contiguous tensors of shapes (n,3), (n,), (n,)")
+            return logits, mx, am
         logits = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         if not want_max:
             return logits, None, None
@@ -98,11 +107,12 @@ class Engine:
             check(lib.cd_forward(self._h, _ptr(x), n, nh, nw, _ptr(logits), _ptr(mx), _ptr(am), self._stream()))
         return (logits, mx, am) if want_max else logits
 
-    def forward_u8(self, frames, chan_order=_lib.CD_BGR, resize=NET_W, want_max=True):
-        """u8 [n,H0,W0,3] -> logits (and max, argmax) with the resize fused into the first layer."""
+    def forward_u8(self, frames, chan_order=_lib.CD_BGR, resize=NET_W, want_max=True, out=None):
+        """u8 [n,H0,W0,3] -> logits (and max, argmax) with the resize fused into the first layer.
+        `out` = (logits, max, argmax) tensors to write into (e.g. slices of clip-long buffers)."""
         n, H0, W0, rs, fs = self._frame_layout(frames)
         nh, nw = output_size(H0, W0, resize)
-        logits, mx, am = self._outputs(n, want_max)
+        logits, mx, am = self._outputs(n, want_max, out)
         check(lib.cd_forward_u8(self._h, _ptr(frames), n, H0, W0, rs, fs, chan_order, nh, nw, _ptr(logits),
                                 _ptr(mx), _ptr(am), self._stream()))
         return (logits, mx, am) if want_max else logits
@@ -142,6 +152,18 @@ class Engine:
             raise _lib.CutdetError(_lib.CD_ECAP, f"{s} segments exceed capacity {cap}")
         return {"end_frames": end[:s], "frame_types": typ[:s], "run_lengths": rl[:s], "start_frames": st[:s],
                 "score_means": mean[:s], "score_sums": ssum[:s]}
+
+    def timing_enable(self, on=True):
+        check(lib.cd_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        """{stage: (launches, total_ms)} for the launches bracketed since the last read (syncs)."""
+        out = {}
+        for i, name in enumerate(_lib.STAGES):
+            k, ms = C.c_int64(0), C.c_double(0.0)
+            check(lib.cd_timing_read(self._h, i, C.byref(k), C.byref(ms)))
+            out[name] = (k.value, ms.value)
+        return out
 
     def synth_frames(self, classes, H0, W0, seed=1234, first_index=0, out=None):
         """Deterministic synthetic clip: u8 [n,H0,W0,3] for per-frame class ids (device u8 tensor)."""

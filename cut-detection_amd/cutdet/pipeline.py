@@ -1,0 +1,105 @@
+"""Clip-level pipeline: u8 frames resident on the GPU -> per-frame streams -> segments -> CSV.
+
+This is the data path of the reference's driver loop (segment_video.py:38-77) with the tensor
+work moved into the native library: batches of decoded frames go through the fused
+resize+classify call, the argmax/max streams stay on the GPU in clip-long buffers, and one
+run-length pass plus the host-side repair turns them into the CSV rows.
+
+With several ranks (one process per GPU, frames sharded by contiguous range) the only
+exchange is one all-gather of the per-frame (class, max) streams -- 12 bytes per frame -- after
+which rank 0 segments the whole clip exactly as a single GPU would.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CLASS_NAMES = ("a22", "ez", "b")   # ids 0, 1, 2 (reference frameID/data.py:116)
+TABLE_KEYS = ("end_frames", "frame_types", "run_lengths", "start_frames", "score_means")
+
+
+def glue_and_merge(table, real_threshold=100, blank_threshold=10, steps=3):
+    """Host pass over a segment table {key: numpy array}; returns a new table.
+    steps: bit 0 glue orphans (reference segmentation.py:91-166), bit 1 merge equal
+    neighbours (:168-183).  Raises IndexError where the reference does."""
+    a = {k: np.ascontiguousarray(table[k]).copy() for k in TABLE_KEYS}
+    n = C.c_int64(a["end_frames"].shape[0])
+    p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = _lib.lib.cd_glue_segments(p(a["end_frames"]), p(a["frame_types"]), p(a["run_lengths"]),
+                                   p(a["start_frames"]), p(a["score_means"]), C.byref(n),
+                                   int(real_threshold), int(blank_threshold), int(steps))
+    if rc != _lib.CD_OK:
+        msg = (_lib.lib.cd_last_error() or b"").decode()
+        if "index out of bounds" in msg:
+            raise IndexError("index 1 is out of bounds for dimension 0 with size 1")
+        raise _lib.CutdetError(rc, msg)
+    return {k: a[k][: n.value] for k in TABLE_KEYS}
+
+
+def csv_bytes(table):
+    """`start,type` rows with CRLF line ends and no header (reference segmentation.py:185-196)."""
+    return b"".join(b"%d,%s\r\n" % (int(s), CLASS_NAMES[int(t)].encode())
+                    for s, t in zip(table["start_frames"], table["frame_types"]))
+
+
+def gather_streams(cls, maxv, group=None):
+    """(cls, maxv) of the whole clip on every rank: each rank's streams all-gathered in rank order.
+    Ranks may hold different counts; payloads are padded to the largest.  Works on any backend
+    (RCCL for GPU tensors, gloo for CPU tensors); without an initialised process group it is the
+    identity."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return cls, maxv
+    world = dist.get_world_size(group)
+    if world == 1:
+        return cls, maxv
+    dev = cls.device
+    n_local = cls.shape[0]
+    counts = torch.zeros((world,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
+    counts = counts.tolist()
+    cap = max(counts)
+    # one payload per rank: [cap] int64 classes followed by [cap] float32 maxima, as bytes
+    pay = torch.zeros((cap * 12,), dtype=torch.uint8, device=dev)
+    pay[: n_local * 8] = cls.contiguous().view(torch.uint8)
+    pay[cap * 8: cap * 8 + n_local * 4] = maxv.contiguous().view(torch.uint8)
+    allpay = torch.empty((world * cap * 12,), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(allpay, pay, group=group)
+    allpay = allpay.view(world, cap * 12)
+    out_cls = torch.cat([allpay[r, : counts[r] * 8].view(torch.int64) for r in range(world)])
+    out_max = torch.cat([allpay[r, cap * 8: cap * 8 + counts[r] * 4].view(torch.float32) for r in range(world)])
+    return out_cls, out_max
+
+
+class ClipClassifier:
+    """Classifies a clip batch by batch into clip-long device buffers, then segments it."""
+
+    def __init__(self, engine, n_frames):
+        self.engine = engine
+        self.n_frames = int(n_frames)
+        dev = engine.device
+        self.logits = torch.empty((self.n_frames, 3), dtype=torch.float32, device=dev)
+        self.maxv = torch.empty((self.n_frames,), dtype=torch.float32, device=dev)
+        self.cls = torch.empty((self.n_frames,), dtype=torch.int64, device=dev)
+
+    def classify(self, frames_u8, offset, chan_order=_lib.CD_BGR):
+        """frames_u8: u8 [b,H0,W0,3] on the GPU; results land at rows offset .. offset+b."""
+        b = frames_u8.shape[0]
+        sl = slice(offset, offset + b)
+        self.engine.forward_u8(frames_u8, chan_order=chan_order,
+                               out=(self.logits[sl], self.maxv[sl], self.cls[sl]))
+
+    def gathered_streams(self, n_local, group=None):
+        return gather_streams(self.cls[:n_local], self.maxv[:n_local], group)
+
+    def segment(self, n_local=None, real_threshold=100, blank_threshold=10, group=None, frame_offset=0):
+        """Segments the (gathered) clip.  Returns {"initial", "glued", "merged": tables, "csv": bytes}."""
+        n_local = self.n_frames if n_local is None else int(n_local)
+        cls, mx = self.gathered_streams(n_local, group)
+        dev = self.engine.rle(cls, mx, frame_offset=frame_offset)
+        initial = {k: dev[k].cpu().numpy() for k in TABLE_KEYS}
+        glued = glue_and_merge(initial, real_threshold, blank_threshold, steps=1)
+        merged = glue_and_merge(glued, real_threshold, blank_threshold, steps=2)
+        return {"initial": initial, "glued": glued, "merged": merged, "csv": csv_bytes(merged)}

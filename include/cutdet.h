@@ -35,6 +35,16 @@ enum {
     CD_ENOMEM = -4
 };
 
+/* pipeline stages, for cd_timing_read() */
+enum {
+    CD_STAGE_PREPROCESS = 0,
+    CD_STAGE_CONV1 = 1,      /* block 1 (with the fused resize when called through cd_forward_u8) */
+    CD_STAGE_CONV2 = 2,      /* block 2: 60 % of the network's FLOPs */
+    CD_STAGE_CONV3_HEAD = 3, /* block 3 + pooling + both linear layers + max/argmax */
+    CD_STAGE_RLE = 4,        /* the four run-length kernels of one cd_rle call */
+    CD_STAGE_COUNT = 5
+};
+
 enum { CD_F32 = 0 };                     /* arithmetic type of the forward pass */
 enum { CD_BGR = 0, CD_RGB = 1 };         /* channel order of u8 frames in memory */
 
@@ -95,6 +105,13 @@ int cd_rle(cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64
  * green, 2 near-black) and global index first_index + i.  No counterpart in the reference. */
 int cd_synth_frames(cd_handle* h, uint8_t* dst, int n, int H0, int W0,
                     const uint8_t* classes, uint32_t seed, int64_t first_index, void* stream);
+
+/* Per-stage device timing.  While enabled, every stage launch is bracketed by a pair of HIP
+ * events on the caller's stream.  cd_timing_read() waits for the recorded events of `stage`,
+ * returns how many launches were bracketed and their summed duration, and forgets them.
+ * No counterpart in the reference; used by bench.py for the per-kernel roofline figures. */
+int cd_timing_enable(cd_handle* h, int on);
+int cd_timing_read(cd_handle* h, int stage, int64_t* launches, double* total_ms);
 
 /* Host-side orphan gluing + adjacent merge on a segment table in host memory, in place.
  * Replaces frameID/segmentation.py:91-166 glue_orphans() and :168-183
