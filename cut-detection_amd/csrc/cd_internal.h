@@ -60,9 +60,10 @@ struct cd_handle {
     cd::ResizeTables rt;
     void* table_mem;        // one allocation behind rt.*
     void* param_mem;        // one allocation behind p.*
-    float* act1;            // workspace: [frames][h1][85][48]
-    float* act2;            // workspace: [frames][h2][28][48]
+    float* act1;            // workspace: [frames+1][h1+2][87][48], zero border around each frame
+    float* act2;            // workspace: [frames+1][h2+2][30][48], zero border around each frame
     size_t act1_bytes, act2_bytes;
+    int ws_h;               // network input height the borders are laid out for
     int64_t* rle_blocks;    // workspace of cd_rle: per-block boundary counts / offsets
     int rle_blocks_cap;
     // optional per-stage timing: HIP event pairs recorded around each stage's launches

@@ -162,10 +162,14 @@ int ensure_tables(cd_handle* h, int H0, int W0, int nh, int nw, hipStream_t s) {
     return CD_OK;
 }
 
+// Activations are stored with a one-pixel zero border per frame, plus one frame of slack at the
+// end so that clamped reads of partial tiles stay inside the allocation.  The whole buffer is
+// zeroed once here; the kernels only ever write interior cells, so the border stays zero.
 int ensure_workspace(cd_handle* h, int n, const Geometry& g, hipStream_t s) {
-    const size_t need1 = (size_t)n * g.h1 * kW1 * kC * sizeof(float);
-    const size_t need2 = (size_t)n * g.h2 * kW2 * kC * sizeof(float);
-    if (need1 <= h->act1_bytes && need2 <= h->act2_bytes) return CD_OK;
+    const size_t need1 = (size_t)(n + 1) * (g.h1 + 2) * (kW1 + 2) * kC * sizeof(float);
+    const size_t need2 = (size_t)(n + 1) * (g.h2 + 2) * (kW2 + 2) * kC * sizeof(float);
+    const bool same_shape = h->ws_h == g.h;
+    if (same_shape && need1 <= h->act1_bytes && need2 <= h->act2_bytes) return CD_OK;
     CD_HIP(hipStreamSynchronize(s));
     if (need1 > h->act1_bytes) {
         if (h->act1) CD_HIP(hipFree(h->act1));
@@ -179,6 +183,10 @@ int ensure_workspace(cd_handle* h, int n, const Geometry& g, hipStream_t s) {
         CD_HIP(hipMalloc(reinterpret_cast<void**>(&h->act2), need2));
         h->act2_bytes = need2;
     }
+    // a different input height moves the borders: re-zero everything
+    CD_HIP(hipMemsetAsync(h->act1, 0, h->act1_bytes, s));
+    CD_HIP(hipMemsetAsync(h->act2, 0, h->act2_bytes, s));
+    h->ws_h = g.h;
     return CD_OK;
 }
 

@@ -14,8 +14,15 @@
 // 3x3 max, the bias and the BatchNorm affine all happen in registers and only the pooled
 // tensor is ever written (the reference materialises the full conv output, net.py:35-38).
 //
-// Activations between blocks are channel-last ([frame][row][col][48] fp32) so that one 16-byte
-// LDS read gives a lane the A values of four consecutive k-steps.
+// Activations between blocks are channel-last fp32 with a one-pixel zero border stored in HBM
+// ([frame][rows+2][cols+2][48]; the border is zeroed when the workspace is allocated and never
+// written), so that the next block's 3x3 taps need no bounds checks, its input tile is a plain
+// strided copy (LDS-DMA), and one 16-byte LDS read gives a lane the A values of four
+// consecutive k-steps.
+//
+// Workgroup -> work mapping is XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so
+// workgroup b works on frame (b % 8) + 8 * (...): all tiles of one frame run on one XCD and
+// share its L2 for tile halos and weights.  This only affects speed.
 #include "cd_sample.h"
 
 namespace cd {
@@ -51,20 +58,33 @@ constexpr int kC1RS = 260;                 // LDS row stride (floats); columns -
 constexpr int kC1Tile = kInC * kC1Rows * kC1RS;
 constexpr int kC1PoolRows = 3;
 constexpr int kC1Windows = kC1PoolRows * kW1;   // 255
+constexpr int kP1W = kW1 + 2;              // padded width of the block-1 output in HBM (87)
+constexpr int kP2W = kW2 + 2;              // padded width of the block-2 output in HBM (30)
 
+// frame / tile of workgroup b when `per_frame` workgroups make up a frame (XCD-aware order)
+__device__ __forceinline__ void xcd_frame_tile(int b, int per_frame, int& frame, int& tile) {
+    const int xcd = b & 7, i = b >> 3;
+    frame = xcd + 8 * (i / per_frame);
+    tile = i % per_frame;
+}
+
+// MODE 0: fp32 NCHW input.  MODE 1: u8 source, pure point sample.  MODE 2: u8 source, general
+// fixed-point bilinear / 2x2 box (sample_u8).
 template <int MODE>
 __global__ __launch_bounds__(256) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
     int chan_order, const float* __restrict__ lut, const float* __restrict__ wfrag,
-    const float* __restrict__ post, float* __restrict__ out, int H, int Hp, int chunks) {
+    const float* __restrict__ post, float* __restrict__ out, int n, int H, int Hp, int chunks) {
     __shared__ float tile[kC1Tile];
-    __shared__ float slut[MODE == 1 ? 256 : 1];
+    __shared__ float slut[MODE != 0 ? 256 : 1];
     const int tid = threadIdx.x;
-    const int frame = blockIdx.x / chunks;
-    const int py0 = (blockIdx.x % chunks) * kC1PoolRows;
+    int frame, chunk;
+    xcd_frame_tile(blockIdx.x, chunks, frame, chunk);
+    if (frame >= n) return;
+    const int py0 = chunk * kC1PoolRows;
     const int gy0 = 3 * py0 - 1;           // input row held in LDS row 0
 
-    if (MODE == 1) { slut[tid] = lut[tid]; __syncthreads(); }
+    if (MODE != 0) { slut[tid] = lut[tid]; __syncthreads(); }
     if (MODE == 0) {
         const float* fx = x + (int64_t)frame * kInC * H * kNetW;
         for (int idx = tid; idx < kInC * kC1Rows * 258; idx += 256) {
@@ -76,16 +96,40 @@ __global__ __launch_bounds__(256) void conv1_kernel(
             tile[(ci * kC1Rows + r) * kC1RS + c] = v;
         }
     } else {
+        // Thread t owns LDS column t (network column t-1) for all 11 rows; thread 0 also takes
+        // column 256.  All byte loads of a column are issued before any is used, so one round of
+        // memory latency covers the whole tile.
         const uint8_t* fsrc = src + (int64_t)frame * frame_stride;
-        for (int idx = tid; idx < kC1Rows * 258; idx += 256) {
-            int c = idx % 258, r = idx / 258;
-            int gy = gy0 + r, gx = c - 1;
-            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < kNetW;
+        const bool bgr = chan_order == CD_BGR;     // memory channel of R is 2 (BGR) or 0 (RGB)
+        for (int c = tid; c < 257; c += 256) {
+            const int gx = c - 1;
+            const bool xin = gx >= 0 && gx < kNetW;
+            uint8_t v[kC1Rows][3];
+            if (MODE == 1) {
+                const int xo = xin ? sa.sx[gx] * 3 : 0;
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                float v = 0.f;
-                if (inside) v = slut[sample_u8(fsrc, gy, gx, chan_order == CD_BGR ? 2 - ci : ci, sa)];
-                tile[(ci * kC1Rows + r) * kC1RS + c] = v;
+                for (int r = 0; r < kC1Rows; ++r) {
+                    const int gy = gy0 + r;
+                    const bool in = xin && gy >= 0 && gy < H;
+                    const uint8_t* p = fsrc + (int64_t)sa.sy[min(max(gy, 0), H - 1)] * sa.row_stride + xo;
+                    v[r][0] = in ? p[0] : (uint8_t)0;
+                    v[r][1] = in ? p[1] : (uint8_t)0;
+                    v[r][2] = in ? p[2] : (uint8_t)0;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < kC1Rows; ++r) {
+                    const int gy = gy0 + r;
+                    const bool in = xin && gy >= 0 && gy < H;
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) v[r][cc] = in ? (uint8_t)sample_u8(fsrc, gy, gx, cc, sa) : (uint8_t)0;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kC1Rows; ++r) {      // slut[0] == 0.0f, so padding cells come out as zeros
+                tile[(0 * kC1Rows + r) * kC1RS + c] = slut[bgr ? v[r][2] : v[r][0]];
+                tile[(1 * kC1Rows + r) * kC1RS + c] = slut[v[r][1]];
+                tile[(2 * kC1Rows + r) * kC1RS + c] = slut[bgr ? v[r][0] : v[r][2]];
             }
         }
     }
@@ -107,6 +151,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(
     }
 
     const int q = lane >> 4, ch = lane & 15;
+    float* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
     for (int wt = wave; wt < 16; wt += 4) {
         const int w0 = wt * 16;
         int base[3];
@@ -151,19 +196,20 @@ __global__ __launch_bounds__(256) void conv1_kernel(
                 int py = py0 + W / kW1, px = W % kW1;
                 if (W < kC1Windows && py < Hp) {
                     float v = fmaxf(m[wi] + bias, 0.f);
-                    out[(((int64_t)frame * Hp + py) * kW1 + px) * kC + c] = fmaf(v, sc, sh);
+                    fout[((int64_t)(py + 1) * kP1W + px + 1) * kC + c] = fmaf(v, sc, sh);
                 }
             }
         }
     }
 }
 
+static unsigned xcd_grid(int n, int per_frame) { return (unsigned)(((n + 7) / 8) * 8 * per_frame); }
+
 int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s) {
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
     SampleArgs sa{};
-    hipLaunchKernelGGL(conv1_kernel<0>, dim3((unsigned)(n * chunks)), dim3(256), 0, s, x,
-                       (const uint8_t*)nullptr, sa, (int64_t)0, 0, (const float*)nullptr, h->p.w1, h->p.post,
-                       h->act1, g.h, g.h1, chunks);
+    hipLaunchKernelGGL(conv1_kernel<0>, dim3(xcd_grid(n, chunks)), dim3(256), 0, s, x, (const uint8_t*)nullptr, sa,
+                       (int64_t)0, 0, (const float*)nullptr, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -172,9 +218,9 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
                     int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s) {
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
     SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride};
-    hipLaunchKernelGGL(conv1_kernel<1>, dim3((unsigned)(n * chunks)), dim3(256), 0, s, (const float*)nullptr,
-                       src, sa, frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->act1, g.h, g.h1,
-                       chunks);
+    auto kern = h->rt.mode == 1 ? conv1_kernel<1> : conv1_kernel<2>;
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(n, chunks)), dim3(256), 0, s, (const float*)nullptr, src, sa,
+                       frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -187,6 +233,7 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
 // k-step e of step (ky, kx, g) therefore covers input channels 16 g + 4 kq + e (kq = 0..3);
 // the packed weights use the same order.  wl points at this lane's first B fragment.
 // ------------------------------------------------------------------------------------------
+template <int UNROLL_KK>
 __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (&base)[3], int pitch,
                                                  const f32x4* __restrict__ wl, f32x4 (&acc)[3][3][3]) {
 #pragma unroll
@@ -195,7 +242,7 @@ __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll UNROLL_KK
     for (int kk = 0; kk < 9; ++kk) {
         const int kkoff = ((kk / 3) * pitch + (kk % 3)) * kC;
 #pragma unroll
@@ -228,28 +275,36 @@ __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (
 // wave per SIMD, each issuing 2916 back-to-back MFMAs per tile.
 // ------------------------------------------------------------------------------------------
 constexpr int kP2 = 14;
+constexpr int kP2Bytes = kP2 * kP2 * kC * 4;   // 37632
 
 __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                    const float* __restrict__ wfrag,
-                                                   const float* __restrict__ post, int Hin, int Win, int Hp,
-                                                   int Wp, int tiles_x, int tiles_y) {
+                                                   const float* __restrict__ post, int n, int Hin, int Hp,
+                                                   int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float patch[kP2 * kP2 * kC];
     const int lane = threadIdx.x;
-    const int tiles = tiles_x * tiles_y;
-    const int frame = blockIdx.x / tiles;
-    const int tt = blockIdx.x % tiles;
+    int frame, tt;
+    xcd_frame_tile(blockIdx.x, tiles_x * tiles_y, frame, tt);
+    if (frame >= n) return;
     const int ty = tt / tiles_x, tx = tt % tiles_x;
-    const int y0 = ty * 12 - 1, x0 = tx * 12 - 1;
-    const float* fin = in + (int64_t)frame * Hin * Win * kC;
+    // padded input frame [Hin+2][87][48]; the patch starts at padded (12 ty, 12 tx)
+    const char* fin = reinterpret_cast<const char*>(in + (int64_t)frame * (Hin + 2) * kP1W * kC);
 
-    for (int idx = lane; idx < kP2 * kP2 * (kC / 4); idx += 64) {
-        int pix = idx / (kC / 4), c4 = idx % (kC / 4);
-        int gy = y0 + pix / kP2, gx = x0 + pix % kP2;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win)
-            v = *reinterpret_cast<const f32x4*>(fin + ((int64_t)gy * Win + gx) * kC + 4 * c4);
-        *reinterpret_cast<f32x4*>(patch + pix * kC + 4 * c4) = v;
+    // LDS-DMA: 37 wave-wide 16-byte copies, LDS image linear ([pixel][48 floats]); each lane
+    // works out which pixel/channel chunk its 16 bytes belong to.  Rows past the frame are clamped
+    // (they only feed pool windows that are not stored).
+#pragma unroll
+    for (int it = 0; it < (kP2Bytes + 1023) / 1024; ++it) {
+        const int off = it * 1024 + lane * 16;
+        const int pix = off / (kC * 4), rem = off % (kC * 4);
+        const int r = min(12 * ty + pix / kP2, Hin + 1), c = min(12 * tx + pix % kP2, kP1W - 1);
+        const char* g = fin + ((int64_t)(r * kP1W + c) * kC * 4 + rem);
+        if (off < kP2Bytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)((char*)patch + it * 1024),
+                                             16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int i = lane & 15, kq = lane >> 4;
@@ -257,10 +312,11 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
 #pragma unroll
     for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * kC + 4 * kq;
     f32x4 acc[3][3][3];
-    conv48_wave_tile(patch, base, kP2, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
+    conv48_wave_tile<9>(patch, base, kP2, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
 
     const int q = lane >> 4, ch = lane & 15;
     const int py = ty * 4 + q;
+    float* fout = out + (int64_t)frame * (Hp + 2) * kP2W * kC;
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
         const int c = nt * 16 + ch;
@@ -270,9 +326,9 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
 #pragma unroll
         for (int wi = 0; wi < 4; ++wi) {
             int px = tx * 4 + wi;
-            if (py < Hp && px < Wp) {
+            if (py < Hp && px < kW2) {
                 float v = fmaxf(m[wi] + bias, 0.f);
-                out[(((int64_t)frame * Hp + py) * Wp + px) * kC + c] = fmaf(v, sc, sh);
+                fout[((int64_t)(py + 1) * kP2W + px + 1) * kC + c] = fmaf(v, sc, sh);
             }
         }
     }
@@ -280,8 +336,8 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
 
 int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
-    hipLaunchKernelGGL(conv2_kernel, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(64), 0, s, h->act1, h->act2,
-                       h->p.w2, h->p.post + 3 * kC, g.h1, kW1, g.h2, kW2, tiles_x, tiles_y);
+    hipLaunchKernelGGL(conv2_kernel, dim3(xcd_grid(n, tiles_x * tiles_y)), dim3(64), 0, s, h->act1, h->act2, h->p.w2,
+                       h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -309,16 +365,16 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     float* hid = feat + kFeat;                            // [32]
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
-    const float* fin = in + (int64_t)frame * Hin * kW2 * kC;
-
-    for (int idx = tid; idx < (Hin + 2) * kP3W * (kC / 4); idx += 256) {
-        int pix = idx / (kC / 4), c4 = idx % (kC / 4);
-        int gy = pix / kP3W - 1, gx = pix % kP3W - 1;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < Hin && gx >= 0 && gx < kW2)
-            v = *reinterpret_cast<const f32x4*>(fin + ((int64_t)gy * kW2 + gx) * kC + 4 * c4);
-        *reinterpret_cast<f32x4*>(patch + pix * kC + 4 * c4) = v;
+    // the padded block-2 activation of this frame is contiguous in HBM: a linear LDS-DMA copy
+    const char* fin = reinterpret_cast<const char*>(in + (int64_t)frame * (Hin + 2) * kP3W * kC);
+    const int patch_bytes = (Hin + 2) * kP3W * kC * 4;
+    for (int off0 = (tid >> 6) * 1024; off0 < patch_bytes; off0 += 4096) {
+        const int off = off0 + (tid & 63) * 16;
+        if (off < patch_bytes)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fin + off),
+                                             (__attribute__((address_space(3))) void*)((char*)patch + off0), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -339,7 +395,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
         f32x4 acc[3][3][3];
         // columns of one lane's 12 may straddle pool rows here, so tile (t, j) of lane-row i uses
         // base[j] for every t and the conv row offset t is applied inside the tile routine
-        conv48_wave_tile(patch, base, kP3W, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
+        conv48_wave_tile<1>(patch, base, kP3W, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int c = nt * 16 + ch;
