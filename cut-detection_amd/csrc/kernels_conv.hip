@@ -68,76 +68,113 @@ __device__ __forceinline__ void xcd_frame_tile(int b, int per_frame, int& frame,
     tile = i % per_frame;
 }
 
-// MODE 0: fp32 NCHW input.  MODE 1: u8 source, pure point sample.  MODE 2: u8 source, general
-// fixed-point bilinear / 2x2 box (sample_u8).
+// 4-byte load at any byte address (the hardware handles unaligned global loads)
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+constexpr int kC1ChunksPerWG = 4;          // consecutive 3-pool-row chunks one workgroup walks
+
+// Staging helpers -------------------------------------------------------------------------
+// Thread t owns LDS column t (network column t-1) for all 11 rows; threads 0..10 also own one
+// cell of column 256 (row = t).
+
+// MODE 1 fetch: one unaligned dword per cell (its low 3 bytes, after a shift, are the pixel).
+// Nothing here waits for the loads: the values are first touched in point_commit().
+struct PointRaw { uint32_t v[kC1Rows + 1]; int sh, sh_x; };
+
+__device__ __forceinline__ void point_fetch(const uint8_t* __restrict__ fsrc, const SampleArgs& sa, int gy0,
+                                            int H, int tid, PointRaw& raw) {
+    const int last = sa.W0 * 3 - 4;            // last byte offset a 4-byte load may start at
+    const int gx = tid - 1;
+    const bool xin = gx >= 0;
+    const int xo = xin ? sa.sx[gx] * 3 : 0;
+    const int a = min(xo, last);
+    raw.sh = (xo - a) * 8;
+#pragma unroll
+    for (int r = 0; r < kC1Rows; ++r) {
+        const int gy = gy0 + r;
+        const uint8_t* p = fsrc + (int64_t)sa.sy[min(max(gy, 0), H - 1)] * sa.row_stride + a;
+        raw.v[r] = (xin && gy >= 0 && gy < H) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
+    }
+    {   // column 256 (network column 255), row tid
+        const int xo2 = sa.sx[kNetW - 1] * 3, a2 = min(xo2, last);
+        raw.sh_x = (xo2 - a2) * 8;
+        const int gy = gy0 + tid;
+        const uint8_t* p = fsrc + (int64_t)sa.sy[min(max(gy, 0), H - 1)] * sa.row_stride + a2;
+        raw.v[kC1Rows] = (tid < kC1Rows && gy >= 0 && gy < H) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
+    }
+}
+
+__device__ __forceinline__ void put_pixel(float* tile, const float* slut, int r, int c, uint32_t px, bool bgr) {
+    const uint32_t b0 = px & 255u, b1 = (px >> 8) & 255u, b2 = (px >> 16) & 255u;
+    tile[(0 * kC1Rows + r) * kC1RS + c] = slut[bgr ? b2 : b0];     // R plane (slut[0] == 0: padding)
+    tile[(1 * kC1Rows + r) * kC1RS + c] = slut[b1];
+    tile[(2 * kC1Rows + r) * kC1RS + c] = slut[bgr ? b0 : b2];
+}
+
+__device__ __forceinline__ void point_commit(float* tile, const float* slut, int tid, const PointRaw& raw, bool bgr) {
+#pragma unroll
+    for (int r = 0; r < kC1Rows; ++r) put_pixel(tile, slut, r, tid, raw.v[r] >> raw.sh, bgr);
+    if (tid < kC1Rows) put_pixel(tile, slut, tid, 256, raw.v[kC1Rows] >> raw.sh_x, bgr);
+}
+
+// MODE 2: general fixed-point bilinear / 2x2 box, straight into LDS.
+__device__ __forceinline__ void generic_stage(float* tile, const float* slut, const uint8_t* __restrict__ fsrc,
+                                              const SampleArgs& sa, int gy0, int H, int tid, bool bgr) {
+    for (int c = tid; c < 257; c += 256) {
+        const int gx = c - 1;
+        for (int r = 0; r < kC1Rows; ++r) {
+            const int gy = gy0 + r;
+            uint32_t px = 0;
+            if (gx >= 0 && gy >= 0 && gy < H)
+                px = (uint32_t)sample_u8(fsrc, gy, gx, 0, sa) | ((uint32_t)sample_u8(fsrc, gy, gx, 1, sa) << 8) |
+                     ((uint32_t)sample_u8(fsrc, gy, gx, 2, sa) << 16);
+            put_pixel(tile, slut, r, c, px, bgr);
+        }
+    }
+}
+
+// MODE 0: normalised fp32 NCHW input, row-wise copy.
+__device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__ fx, int gy0, int H, int tid) {
+    for (int idx = tid; idx < kInC * kC1Rows * 258; idx += 256) {
+        int c = idx % 258, rr = idx / 258;
+        int r = rr % kC1Rows, ci = rr / kC1Rows;
+        int gy = gy0 + r, gx = c - 1;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < kNetW) v = fx[((int64_t)ci * H + gy) * kNetW + gx];
+        tile[(ci * kC1Rows + r) * kC1RS + c] = v;
+    }
+}
+
+// MODE 0: fp32 NCHW input.  MODE 1: u8 source, pure point sample (every tap weight is 1).
+// MODE 2: u8 source, general resize.
+//
+// A workgroup walks kC1ChunksPerWG consecutive chunks of one frame.  In MODE 1 the source bytes
+// of chunk k+1 are requested (into registers) before the MFMA work of chunk k starts and are
+// converted and written to LDS after it, so the HBM latency of the gather hides under compute.
 template <int MODE>
 __global__ __launch_bounds__(256) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
     int chan_order, const float* __restrict__ lut, const float* __restrict__ wfrag,
-    const float* __restrict__ post, float* __restrict__ out, int n, int H, int Hp, int chunks) {
-    __shared__ float tile[kC1Tile];
+    const float* __restrict__ post, float* __restrict__ out, int n, int H, int Hp, int chunks, int groups) {
+    __shared__ __attribute__((aligned(16))) float tile[kC1Tile];
+    __shared__ __attribute__((aligned(16))) float stage_out[4][16 * kC];   // per-wave epilogue transpose
     __shared__ float slut[MODE != 0 ? 256 : 1];
     const int tid = threadIdx.x;
-    int frame, chunk;
-    xcd_frame_tile(blockIdx.x, chunks, frame, chunk);
+    int frame, grp;
+    xcd_frame_tile(blockIdx.x, groups, frame, grp);
     if (frame >= n) return;
-    const int py0 = chunk * kC1PoolRows;
-    const int gy0 = 3 * py0 - 1;           // input row held in LDS row 0
+    const int chunk0 = grp * kC1ChunksPerWG;
+    const int nchunks = min(kC1ChunksPerWG, chunks - chunk0);
+    const bool bgr = chan_order == CD_BGR;
+    const uint8_t* fsrc = MODE != 0 ? src + (int64_t)frame * frame_stride : nullptr;
+    const float* fx = MODE == 0 ? x + (int64_t)frame * kInC * H * kNetW : nullptr;
 
-    if (MODE != 0) { slut[tid] = lut[tid]; __syncthreads(); }
-    if (MODE == 0) {
-        const float* fx = x + (int64_t)frame * kInC * H * kNetW;
-        for (int idx = tid; idx < kInC * kC1Rows * 258; idx += 256) {
-            int c = idx % 258, rr = idx / 258;
-            int r = rr % kC1Rows, ci = rr / kC1Rows;
-            int gy = gy0 + r, gx = c - 1;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < kNetW) v = fx[((int64_t)ci * H + gy) * kNetW + gx];
-            tile[(ci * kC1Rows + r) * kC1RS + c] = v;
-        }
-    } else {
-        // Thread t owns LDS column t (network column t-1) for all 11 rows; thread 0 also takes
-        // column 256.  All byte loads of a column are issued before any is used, so one round of
-        // memory latency covers the whole tile.
-        const uint8_t* fsrc = src + (int64_t)frame * frame_stride;
-        const bool bgr = chan_order == CD_BGR;     // memory channel of R is 2 (BGR) or 0 (RGB)
-        for (int c = tid; c < 257; c += 256) {
-            const int gx = c - 1;
-            const bool xin = gx >= 0 && gx < kNetW;
-            uint8_t v[kC1Rows][3];
-            if (MODE == 1) {
-                const int xo = xin ? sa.sx[gx] * 3 : 0;
-#pragma unroll
-                for (int r = 0; r < kC1Rows; ++r) {
-                    const int gy = gy0 + r;
-                    const bool in = xin && gy >= 0 && gy < H;
-                    const uint8_t* p = fsrc + (int64_t)sa.sy[min(max(gy, 0), H - 1)] * sa.row_stride + xo;
-                    v[r][0] = in ? p[0] : (uint8_t)0;
-                    v[r][1] = in ? p[1] : (uint8_t)0;
-                    v[r][2] = in ? p[2] : (uint8_t)0;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < kC1Rows; ++r) {
-                    const int gy = gy0 + r;
-                    const bool in = xin && gy >= 0 && gy < H;
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) v[r][cc] = in ? (uint8_t)sample_u8(fsrc, gy, gx, cc, sa) : (uint8_t)0;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < kC1Rows; ++r) {      // slut[0] == 0.0f, so padding cells come out as zeros
-                tile[(0 * kC1Rows + r) * kC1RS + c] = slut[bgr ? v[r][2] : v[r][0]];
-                tile[(1 * kC1Rows + r) * kC1RS + c] = slut[v[r][1]];
-                tile[(2 * kC1Rows + r) * kC1RS + c] = slut[bgr ? v[r][0] : v[r][2]];
-            }
-        }
-    }
-    __syncthreads();
+    if (MODE != 0) slut[tid] = lut[tid];
+    PointRaw raw;
+    if (MODE == 1) point_fetch(fsrc, sa, 9 * chunk0 - 1, H, tid, raw);
 
     const int wave = tid >> 6, lane = tid & 63;
     const int i = lane & 15, kq = lane >> 4;
-
     // B fragments for all 7 k-steps stay in registers for the whole workgroup.
     float bw[7][3];
     int koff[7];
@@ -149,56 +186,82 @@ __global__ __launch_bounds__(256) void conv1_kernel(
         int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
         koff[s] = (ci * kC1Rows + ky) * kC1RS + kx;
     }
-
     const int q = lane >> 4, ch = lane & 15;
     float* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
-    for (int wt = wave; wt < 16; wt += 4) {
-        const int w0 = wt * 16;
-        int base[3];
+    float* my_out = stage_out[wave];
+    __syncthreads();                        // slut visible
+
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int py0 = (chunk0 + kc) * kC1PoolRows;
+        const int gy0 = 3 * py0 - 1;        // input row held in LDS row 0
+        if (kc > 0) __syncthreads();        // every wave is done reading the previous tile
+        if (MODE == 0) f32_stage(tile, fx, gy0, H, tid);
+        else if (MODE == 1) point_commit(tile, slut, tid, raw, bgr);
+        else generic_stage(tile, slut, fsrc, sa, gy0, H, tid, bgr);
+        __syncthreads();
+        if (MODE == 1 && kc + 1 < nchunks) point_fetch(fsrc, sa, gy0 + 9, H, tid, raw);
+
+        for (int wt = wave; wt < 16; wt += 4) {
+            const int w0 = wt * 16;
+            int base[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            int c12 = 4 * j + (i & 3);
-            int W = min(w0 + 4 * (i >> 2) + c12 / 3, kC1Windows - 1);
-            int wrow = W / kW1, px = W % kW1;
-            base[j] = (3 * wrow) * kC1RS + 3 * px + c12 % 3;
-        }
-        f32x4 acc[3][3][3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            float a[3][3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) a[t][j] = tile[base[j] + koff[s] + t * kC1RS];
+            for (int j = 0; j < 3; ++j) {
+                int c12 = 4 * j + (i & 3);
+                int W = min(w0 + 4 * (i >> 2) + c12 / 3, kC1Windows - 1);
+                int wrow = W / kW1, px = W % kW1;
+                base[j] = (3 * wrow) * kC1RS + 3 * px + c12 % 3;
+            }
+            f32x4 acc[3][3][3];
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
 #pragma unroll
-                    for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = mfma4(a[t][j], bw[s][nt], acc[t][j][nt]);
-        }
-        // epilogue: lane (q, ch) owns pool windows w0 + 4q .. w0 + 4q + 3 for channels ch + 16 nt
+                    for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-            const int c = nt * 16 + ch;
-            const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
-            float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
-                          window_max<3>(acc, nt)};
+            for (int s = 0; s < 7; ++s) {
+                float a[3][3];
 #pragma unroll
-            for (int wi = 0; wi < 4; ++wi) {
-                int W = w0 + 4 * q + wi;
-                int py = py0 + W / kW1, px = W % kW1;
-                if (W < kC1Windows && py < Hp) {
-                    float v = fmaxf(m[wi] + bias, 0.f);
-                    fout[((int64_t)(py + 1) * kP1W + px + 1) * kC + c] = fmaf(v, sc, sh);
-                }
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) a[t][j] = tile[base[j] + koff[s] + t * kC1RS];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = mfma4(a[t][j], bw[s][nt], acc[t][j][nt]);
             }
+            // epilogue: lane (q, ch) owns pool windows w0 + 4q .. w0 + 4q + 3 for channels ch + 16 nt;
+            // the 16 x 48 results are transposed through LDS so that each window's 48 channels
+            // (192 contiguous bytes in HBM) leave as 16-byte stores.
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const int c = nt * 16 + ch;
+                const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
+                float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
+                              window_max<3>(acc, nt)};
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) my_out[(4 * q + wi) * kC + c] = fmaf(fmaxf(m[wi] + bias, 0.f), sc, sh);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int f = it * 64 + lane;             // 16-byte piece f of the 16 x 192-byte block
+                const int win = f / 12, c4 = f % 12;
+                const int W = w0 + win;
+                const int py = py0 + W / kW1, px = W % kW1;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + win * kC + 4 * c4);
+#ifdef CD_ABL_EPI
+                if (W < kC1Windows && py < Hp && v[0] == 123456.f)
+#else
+                if (W < kC1Windows && py < Hp)
+#endif
+                    *reinterpret_cast<f32x4*>(fout + ((int64_t)(py + 1) * kP1W + px + 1) * kC + 4 * c4) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next tile rewrites
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -208,8 +271,10 @@ static unsigned xcd_grid(int n, int per_frame) { return (unsigned)(((n + 7) / 8)
 int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s) {
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
     SampleArgs sa{};
-    hipLaunchKernelGGL(conv1_kernel<0>, dim3(xcd_grid(n, chunks)), dim3(256), 0, s, x, (const uint8_t*)nullptr, sa,
-                       (int64_t)0, 0, (const float*)nullptr, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks);
+    const int groups = (chunks + kC1ChunksPerWG - 1) / kC1ChunksPerWG;
+    hipLaunchKernelGGL(conv1_kernel<0>, dim3(xcd_grid(n, groups)), dim3(256), 0, s, x, (const uint8_t*)nullptr, sa,
+                       (int64_t)0, 0, (const float*)nullptr, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks,
+                       groups);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -219,8 +284,11 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
     SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride};
     auto kern = h->rt.mode == 1 ? conv1_kernel<1> : conv1_kernel<2>;
-    hipLaunchKernelGGL(kern, dim3(xcd_grid(n, chunks)), dim3(256), 0, s, (const float*)nullptr, src, sa,
-                       frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks);
+    const int groups = (chunks + kC1ChunksPerWG - 1) / kC1ChunksPerWG;
+    if (W0 < 2) { set_error("cd_forward_u8: source frames must be at least 2 pixels wide"); return CD_EINVAL; }
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(n, groups)), dim3(256), 0, s, (const float*)nullptr, src, sa,
+                       frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks,
+                       groups);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
