@@ -45,6 +45,16 @@ __device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3][3], int nt)
     return m;
 }
 
+template <int WI>
+__device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3]) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int c = 3 * WI; c < 3 * WI + 3; ++c) m = fmaxf(m, acc[t][c >> 2][c & 3]);
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------
 // Block 1: 3 -> 48 channels, K = 27 (padded to 28 = 7 k-steps).
 // One workgroup (4 waves) = 3 pooled rows of one frame = 255 pool windows = 16 wave tiles
@@ -152,12 +162,12 @@ __device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__
 // of chunk k+1 are requested (into registers) before the MFMA work of chunk k starts and are
 // converted and written to LDS after it, so the HBM latency of the gather hides under compute.
 template <int MODE>
-__global__ __launch_bounds__(256) void conv1_kernel(
+__global__ __launch_bounds__(256, 4) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
     int chan_order, const float* __restrict__ lut, const float* __restrict__ wfrag,
     const float* __restrict__ post, float* __restrict__ out, int n, int H, int Hp, int chunks, int groups) {
     __shared__ __attribute__((aligned(16))) float tile[kC1Tile];
-    __shared__ __attribute__((aligned(16))) float stage_out[4][16 * kC];   // per-wave epilogue transpose
+    __shared__ __attribute__((aligned(16))) float stage_out[4][16 * 16];   // per-wave epilogue transpose
     __shared__ float slut[MODE != 0 ? 256 : 1];
     const int tid = threadIdx.x;
     int frame, grp;
@@ -175,13 +185,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(
 
     const int wave = tid >> 6, lane = tid & 63;
     const int i = lane & 15, kq = lane >> 4;
-    // B fragments for all 7 k-steps stay in registers for the whole workgroup.
-    float bw[7][3];
     int koff[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt) bw[s][nt] = wfrag[(s * 3 + nt) * 64 + lane];
         int k = min(4 * s + kq, 26);       // k = 27 is padding: its weight is 0, read a valid cell
         int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
         koff[s] = (ci * kC1Rows + ky) * kC1RS + kx;
@@ -211,57 +217,60 @@ __global__ __launch_bounds__(256) void conv1_kernel(
                 int wrow = W / kW1, px = W % kW1;
                 base[j] = (3 * wrow) * kC1RS + 3 * px + c12 % 3;
             }
-            f32x4 acc[3][3][3];
+            // A-operand addresses of the 7 k-steps x 3 column groups (conv row t is an immediate)
+            int addr[7][3];
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int s = 0; s < 7; ++s)
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 7; ++s) {
-                float a[3][3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) a[t][j] = tile[base[j] + koff[s] + t * kC1RS];
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = mfma4(a[t][j], bw[s][nt], acc[t][j][nt]);
-            }
-            // epilogue: lane (q, ch) owns pool windows w0 + 4q .. w0 + 4q + 3 for channels ch + 16 nt;
-            // the 16 x 48 results are transposed through LDS so that each window's 48 channels
-            // (192 contiguous bytes in HBM) leave as 16-byte stores.
-#pragma unroll
+                for (int j = 0; j < 3; ++j) addr[s][j] = base[j] + koff[s];
+            // One 16-channel group at a time: 9 accumulators live instead of 27, which keeps the
+            // kernel at 3-4 waves per SIMD so that other waves' MFMAs cover this wave's staging,
+            // LDS latency and epilogue.  The A values are re-read from LDS for each group.
+#pragma unroll 1
             for (int nt = 0; nt < 3; ++nt) {
+                f32x4 acc[3][3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 7; ++s) {
+                    const float b = wfrag[(s * 3 + nt) * 64 + lane];
+                    float a[3][3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) a[t][j] = tile[addr[s][j] + t * kC1RS];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc[t][j] = mfma4(a[t][j], b, acc[t][j]);
+                }
+                // epilogue: lane (q, ch) owns pool windows w0 + 4q .. w0 + 4q + 3 for channel ch + 16 nt.
+                // The 16 windows x 16 channels are transposed through 1 KB of LDS so that every lane
+                // stores 16 contiguous bytes (4 channels of one window).
                 const int c = nt * 16 + ch;
                 const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
-                float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
-                              window_max<3>(acc, nt)};
+                float m[4] = {window_max<0>(acc), window_max<1>(acc), window_max<2>(acc), window_max<3>(acc)};
 #pragma unroll
-                for (int wi = 0; wi < 4; ++wi) my_out[(4 * q + wi) * kC + c] = fmaf(fmaxf(m[wi] + bias, 0.f), sc, sh);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int f = it * 64 + lane;             // 16-byte piece f of the 16 x 192-byte block
-                const int win = f / 12, c4 = f % 12;
-                const int W = w0 + win;
-                const int py = py0 + W / kW1, px = W % kW1;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + win * kC + 4 * c4);
+                for (int wi = 0; wi < 4; ++wi) my_out[(4 * q + wi) * 16 + ch] = fmaf(fmaxf(m[wi] + bias, 0.f), sc, sh);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int win = lane >> 2, c4 = lane & 3;     // window, 4-channel piece
+                    const int W = w0 + win;
+                    const int py = py0 + W / kW1, px = W % kW1;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + win * 16 + 4 * c4);
 #ifdef CD_ABL_EPI
-                if (W < kC1Windows && py < Hp && v[0] == 123456.f)
+                    if (W < kC1Windows && py < Hp && v[0] == 123456.f)
 #else
-                if (W < kC1Windows && py < Hp)
+                    if (W < kC1Windows && py < Hp)
 #endif
-                    *reinterpret_cast<f32x4*>(fout + ((int64_t)(py + 1) * kP1W + px + 1) * kC + 4 * c4) = v;
+                        *reinterpret_cast<f32x4*>(fout + ((int64_t)(py + 1) * kP1W + px + 1) * kC + nt * 16 + 4 * c4) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read done before the next group rewrites
+                __builtin_amdgcn_wave_barrier();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next tile rewrites
-            __builtin_amdgcn_wave_barrier();
         }
     }
 }
