@@ -310,8 +310,27 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
 // k-step e of step (ky, kx, g) therefore covers input channels 16 g + 4 kq + e (kq = 0..3);
 // the packed weights use the same order.  wl points at this lane's first B fragment.
 // ------------------------------------------------------------------------------------------
-template <int UNROLL_KK>
-__device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (&base)[3], int pitch,
+// The 27 steps are fully unrolled and software-pipelined by hand: the operands of step s+1 (nine
+// 16-byte LDS reads, three 16-byte weight loads that hit L1/L2) are requested before the 108 MFMAs
+// of step s and first used after them.  The scheduling barriers keep the compiler from sinking
+// the loads down to their first use, which would expose the L2 latency once per step.
+template <int PITCH>
+__device__ __forceinline__ void conv48_load_step(const float* patch, const int (&base)[3],
+                                                 const f32x4* __restrict__ wl, int s, f32x4 (&a)[3][3],
+                                                 f32x4 (&b)[3]) {
+    const int kk = s / 3, g = s % 3;
+    const int off = ((kk / 3) * PITCH + (kk % 3)) * kC + 16 * g;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) b[nt] = wl[(s * 3 + nt) * 64];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            a[t][j] = *reinterpret_cast<const f32x4*>(patch + base[j] + off + t * PITCH * kC);
+}
+
+template <int PITCH>
+__device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (&base)[3],
                                                  const f32x4* __restrict__ wl, f32x4 (&acc)[3][3][3]) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -319,81 +338,118 @@ __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll UNROLL_KK
-    for (int kk = 0; kk < 9; ++kk) {
-        const int kkoff = ((kk / 3) * pitch + (kk % 3)) * kC;
+    f32x4 a[2][3][3], b[2][3];
+    conv48_load_step<PITCH>(patch, base, wl, 0, a[0], b[0]);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            f32x4 b[3];
+    for (int s = 0; s < 27; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < 27) conv48_load_step<PITCH>(patch, base, wl, s + 1, a[cur ^ 1], b[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 3; ++nt) b[nt] = wl[((kk * 3 + g) * 3 + nt) * 64];
-            f32x4 a[3][3];
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    a[t][j] = *reinterpret_cast<const f32x4*>(patch + base[j] + kkoff + t * pitch * kC + 16 * g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < 3; ++nt)
-                            acc[t][j][nt] = mfma4(a[t][j][e], b[nt][e], acc[t][j][nt]);
-        }
+                    for (int nt = 0; nt < 3; ++nt)
+                        acc[t][j][nt] = mfma4(a[cur][t][j][e], b[cur][nt][e], acc[t][j][nt]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Block 2: one single-wave workgroup per 4x4 block of pool windows (12x12 conv pixels).
-// The 14x14x48 input patch (37.6 KB) is staged once; four such workgroups share a CU, one
-// wave per SIMD, each issuing 2916 back-to-back MFMAs per tile.
+// Block 2: persistent single-wave workgroups, four per CU (one wave per SIMD).
+//
+// A wave walks wave tiles (4x4 pool windows = 12x12 conv pixels of one frame).  The K loop runs
+// channel-group outermost: for each 16-channel group the 14x14 input patch of that group
+// (12.25 KB, [pixel][16 floats]) is brought in by LDS-DMA into one of two buffers while the
+// previous group's 972 MFMAs run, so the copy never shows up in the wave's timeline.  The
+// operand prefetch of conv48 (one step ahead) runs straight across group and tile boundaries.
+// VMEM ops complete in issue order, so any wait the compiler places on a weight load that was
+// issued after a DMA also covers that DMA; the explicit vmcnt(0) at each group boundary (where
+// only loads issued a full step earlier are outstanding) makes that ordering unconditional.
 // ------------------------------------------------------------------------------------------
 constexpr int kP2 = 14;
-constexpr int kP2Bytes = kP2 * kP2 * kC * 4;   // 37632
+constexpr int kG2Pix = kP2 * kP2;              // 196 pixels
+constexpr int kG2Floats = kG2Pix * 16;         // one channel group of the patch
+constexpr int kG2Pieces = kG2Pix * 4;          // 16-byte pieces per group patch (784)
+constexpr int kG2Dma = (kG2Pieces + 63) / 64;  // wave-wide DMA instructions per group (13)
 
-__global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                   const float* __restrict__ wfrag,
-                                                   const float* __restrict__ post, int n, int Hin, int Hp,
-                                                   int tiles_x, int tiles_y) {
-    __shared__ __attribute__((aligned(16))) float patch[kP2 * kP2 * kC];
-    const int lane = threadIdx.x;
-    int frame, tt;
-    xcd_frame_tile(blockIdx.x, tiles_x * tiles_y, frame, tt);
-    if (frame >= n) return;
-    const int ty = tt / tiles_x, tx = tt % tiles_x;
-    // padded input frame [Hin+2][87][48]; the patch starts at padded (12 ty, 12 tx)
-    const char* fin = reinterpret_cast<const char*>(in + (int64_t)frame * (Hin + 2) * kP1W * kC);
+struct Conv2Tile { const char* src; float* dst; int ty, tx; };
 
-    // LDS-DMA: 37 wave-wide 16-byte copies, LDS image linear ([pixel][48 floats]); each lane
-    // works out which pixel/channel chunk its 16 bytes belong to.  Rows past the frame are clamped
-    // (they only feed pool windows that are not stored).
+__device__ __forceinline__ void conv2_load_step(const float* buf, const int (&base)[3],
+                                                const f32x4* __restrict__ wl, int g, int kk,
+                                                f32x4 (&a)[3][3], f32x4 (&b)[3]) {
+    const int off = ((kk / 3) * kP2 + (kk % 3)) * 16;
 #pragma unroll
-    for (int it = 0; it < (kP2Bytes + 1023) / 1024; ++it) {
-        const int off = it * 1024 + lane * 16;
-        const int pix = off / (kC * 4), rem = off % (kC * 4);
-        const int r = min(12 * ty + pix / kP2, Hin + 1), c = min(12 * tx + pix % kP2, kP1W - 1);
-        const char* g = fin + ((int64_t)(r * kP1W + c) * kC * 4 + rem);
-        if (off < kP2Bytes)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)((char*)patch + it * 1024),
-                                             16, 0, 0);
+    for (int nt = 0; nt < 3; ++nt) b[nt] = wl[((kk * 3 + g) * 3 + nt) * 64];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            a[t][j] = *reinterpret_cast<const f32x4*>(buf + base[j] + off + t * kP2 * 16);
+}
+
+// LDS-DMA of one channel group of a patch: 13 wave-wide 16-byte copies, LDS image linear.
+__device__ __forceinline__ void conv2_dma_group(const char* src, float* dst, const int (&rel)[kG2Dma], int lane) {
+    char* d = reinterpret_cast<char*>(dst);
+#pragma unroll
+    for (int it = 0; it < kG2Dma; ++it) {
+        if (it < kG2Dma - 1 || lane < kG2Pieces - (kG2Dma - 1) * 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + rel[it]),
+                                             (__attribute__((address_space(3))) void*)(d + it * 1024), 16, 0, 0);
     }
+}
+
+// One (tile, channel group) unit: 9 pipelined steps of 108 MFMAs.  P is the parity of the unit
+// in the wave's running sequence: it fixes, at compile time, which LDS buffer the unit reads
+// (`mine`), which one the next unit's patch is copied into (`other`), and which of the two operand
+// register sets holds step 0 (9 steps flip the set, so parities alternate).
+template <int P>
+__device__ __forceinline__ void conv2_unit(const float* mine, float* other, const char* next_src,
+                                           const int (&rel)[kG2Dma], const int (&base)[3],
+                                           const f32x4* __restrict__ wl, int g, int g_next, int lane,
+                                           f32x4 (&a)[2][3][3], f32x4 (&b)[2][3], f32x4 (&acc)[3][3][3]) {
+    // everything outstanding was issued at least one step (108 MFMAs) ago
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int i = lane & 15, kq = lane >> 4;
-    int base[3];
+    // Pin step 0's operands in their registers: left to itself the compiler re-loads the weights
+    // here instead of carrying them across the loop edge, and the wait for that re-load would also
+    // wait (VMEM completes in order) for the patch copy issued below.
 #pragma unroll
-    for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * kC + 4 * kq;
-    f32x4 acc[3][3][3];
-    conv48_wave_tile<9>(patch, base, kP2, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(a[P][t][j]));
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) asm volatile("" : "+v"(b[P][nt]));
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+        const int c = (P + kk) & 1;
+        if (kk < 8) conv2_load_step(mine, base, wl, g, kk + 1, a[c ^ 1], b[c ^ 1]);
+        else conv2_load_step(other, base, wl, g_next, 0, a[c ^ 1], b[c ^ 1]);
+        // the copy of the next unit's patch goes out behind this step's operand loads, so the wait
+        // for those loads (in-order completion) does not have to cover it
+        if (kk == 0) conv2_dma_group(next_src, other, rel, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt)
+                        acc[t][j][nt] = mfma4(a[c][t][j][e], b[c][nt][e], acc[t][j][nt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
+// pooled + normalised results of one wave tile -> HBM, transposed through `scratch` (3 KB of an
+// idle patch buffer) so that each pool window's 48 channels leave as 16-byte stores
+__device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc)[3][3][3],
+                                               const float* __restrict__ post, const Conv2Tile& t, int Hp,
+                                               int lane) {
     const int q = lane >> 4, ch = lane & 15;
-    const int py = ty * 4 + q;
-    float* fout = out + (int64_t)frame * (Hp + 2) * kP2W * kC;
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
         const int c = nt * 16 + ch;
@@ -401,20 +457,123 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
         float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
                       window_max<3>(acc, nt)};
 #pragma unroll
-        for (int wi = 0; wi < 4; ++wi) {
-            int px = tx * 4 + wi;
-            if (py < Hp && px < kW2) {
-                float v = fmaxf(m[wi] + bias, 0.f);
-                fout[((int64_t)(py + 1) * kP2W + px + 1) * kC + c] = fmaf(v, sc, sh);
-            }
+        for (int wi = 0; wi < 4; ++wi) scratch[(4 * q + wi) * kC + c] = fmaf(fmaxf(m[wi] + bias, 0.f), sc, sh);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int f = it * 64 + lane;                 // 16-byte piece f of 16 windows x 192 bytes
+        const int win = f / 12, c4 = f % 12;
+        const int py = t.ty * 4 + (win >> 2), px = t.tx * 4 + (win & 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + win * kC + 4 * c4);
+        if (py < Hp && px < kW2)
+            *reinterpret_cast<f32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                   const float* __restrict__ wfrag,
+                                                   const float* __restrict__ post, int n, int Hin, int Hp,
+                                                   int tiles_x, int tiles_y, int total_tiles) {
+    __shared__ __attribute__((aligned(16))) float buf0[kG2Floats];
+    __shared__ __attribute__((aligned(16))) float buf1[kG2Floats];
+    const int lane = threadIdx.x;
+    const int per_frame = tiles_x * tiles_y;
+    const int64_t in_frame = (int64_t)(Hin + 2) * kP1W * kC * 4, out_frame = (int64_t)(Hp + 2) * kP2W * kC;
+
+    // tile id -> is it a real tile of this batch? (the grid is rounded up to 8 frames)
+    auto valid = [&](int id) {
+        int frame, tt;
+        xcd_frame_tile(id, per_frame, frame, tt);
+        return id < total_tiles && frame < n;
+    };
+    // tile id -> source patch origin / destination frame; invalid ids map to tile 0 so that the
+    // last look-ahead copy of a wave stays in bounds (its data is never used)
+    auto locate = [&](int id) {
+        int frame = 0, tt = 0;
+        if (valid(id)) xcd_frame_tile(id, per_frame, frame, tt);
+        Conv2Tile t;
+        t.ty = tt / tiles_x; t.tx = tt % tiles_x;
+        t.src = reinterpret_cast<const char*>(in) + frame * in_frame + ((int64_t)(12 * t.ty) * kP1W + 12 * t.tx) * kC * 4;
+        t.dst = out + frame * out_frame;
+        return t;
+    };
+    int id = blockIdx.x;
+    if (!valid(id)) return;
+
+    // per-lane byte offsets of this lane's DMA pieces relative to the patch origin, group 0
+    int rel[kG2Dma];
+#pragma unroll
+    for (int it = 0; it < kG2Dma; ++it) {
+        const int f = it * 64 + lane, pix = f >> 2, c4 = f & 3;
+        rel[it] = ((pix / kP2) * kP1W + pix % kP2) * kC * 4 + c4 * 16;
+    }
+    const int i = lane & 15, kq = lane >> 4;
+    int base[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * 16 + 4 * kq;
+    const f32x4* wl = reinterpret_cast<const f32x4*>(wfrag) + lane;
+
+    Conv2Tile cur = locate(id);
+    int next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
+    Conv2Tile nxt = locate(next_id);
+    conv2_dma_group(cur.src, buf0, rel, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4 a[2][3][3], b[2][3], acc[3][3][3];
+    conv2_load_step(buf0, base, wl, 0, 0, a[0], b[0]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Units alternate parity; a tile is three units, so tile boundaries fall on either parity.
+    int g = 0;
+    bool done = false;
+    auto after_unit = [&](float* scratch) {      // returns true when the wave has no more tiles
+        if (g < 2) { ++g; return false; }
+        conv2_epilogue(scratch, acc, post, cur, Hp, lane);
+        if (next_id < 0) return true;
+        id = next_id;
+        cur = nxt;
+        next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
+        nxt = locate(next_id);
+        g = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        return false;
+    };
+    while (!done) {
+        {
+            const char* nsrc = g < 2 ? cur.src + (g + 1) * 64 : nxt.src;
+            conv2_unit<0>(buf0, buf1, nsrc, rel, base, wl, g, g < 2 ? g + 1 : 0, lane, a, b, acc);
+            done = after_unit(buf0);
+        }
+        if (done) break;
+        {
+            const char* nsrc = g < 2 ? cur.src + (g + 1) * 64 : nxt.src;
+            conv2_unit<1>(buf1, buf0, nsrc, rel, base, wl, g, g < 2 ? g + 1 : 0, lane, a, b, acc);
+            done = after_unit(buf1);
         }
     }
+    // the look-ahead copy and operand loads of a unit that will never run are still in flight
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
-    hipLaunchKernelGGL(conv2_kernel, dim3(xcd_grid(n, tiles_x * tiles_y)), dim3(64), 0, s, h->act1, h->act2, h->p.w2,
-                       h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y);
+    const int total = (int)xcd_grid(n, tiles_x * tiles_y);
+    const int grid = total < 1024 ? total : 1024;     // 4 single-wave workgroups per CU, 256 CUs
+    hipLaunchKernelGGL(conv2_kernel, dim3((unsigned)grid), dim3(64), 0, s, h->act1, h->act2, h->p.w2,
+                       h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -472,7 +631,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
         f32x4 acc[3][3][3];
         // columns of one lane's 12 may straddle pool rows here, so tile (t, j) of lane-row i uses
         // base[j] for every t and the conv row offset t is applied inside the tile routine
-        conv48_wave_tile<1>(patch, base, kP3W, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
+        conv48_wave_tile<kP3W>(patch, base, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int c = nt * 16 + ch;
