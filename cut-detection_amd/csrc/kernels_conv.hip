@@ -29,6 +29,19 @@ namespace cd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kW48Bytes = 27 * 3 * 64 * 16;    // packed B fragments of one 48 -> 48 layer
+
+// Weight fragments are read through a buffer descriptor: the address is one per-lane VGPR
+// (lane * 16) plus a scalar offset, so the 81 loads of a tile cost no vector address arithmetic
+// and nothing for the compiler to hoist into registers.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float* w) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, kW48Bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 load_frag(__amdgpu_buffer_rsrc_t r, int lane16, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, byte_off, 0));
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -308,7 +321,7 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
 // values for the 4 k-steps of a step are one ds_read_b128 at
 //     patch[base[j] + ((t + ky) * pitch + kx) * kC + 16 g],   base[j] includes 4 * (lane >> 4).
 // k-step e of step (ky, kx, g) therefore covers input channels 16 g + 4 kq + e (kq = 0..3);
-// the packed weights use the same order.  wl points at this lane's first B fragment.
+// the packed weights use the same order.
 // ------------------------------------------------------------------------------------------
 // The 27 steps are fully unrolled and software-pipelined by hand: the operands of step s+1 (nine
 // 16-byte LDS reads, three 16-byte weight loads that hit L1/L2) are requested before the 108 MFMAs
@@ -316,12 +329,12 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
 // the loads down to their first use, which would expose the L2 latency once per step.
 template <int PITCH>
 __device__ __forceinline__ void conv48_load_step(const float* patch, const int (&base)[3],
-                                                 const f32x4* __restrict__ wl, int s, f32x4 (&a)[3][3],
+                                                 __amdgpu_buffer_rsrc_t wr, int lane16, int s, f32x4 (&a)[3][3],
                                                  f32x4 (&b)[3]) {
     const int kk = s / 3, g = s % 3;
     const int off = ((kk / 3) * PITCH + (kk % 3)) * kC + 16 * g;
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) b[nt] = wl[(s * 3 + nt) * 64];
+    for (int nt = 0; nt < 3; ++nt) b[nt] = load_frag(wr, lane16, (s * 3 + nt) * 1024);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -331,7 +344,7 @@ __device__ __forceinline__ void conv48_load_step(const float* patch, const int (
 
 template <int PITCH>
 __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (&base)[3],
-                                                 const f32x4* __restrict__ wl, f32x4 (&acc)[3][3][3]) {
+                                                 __amdgpu_buffer_rsrc_t wr, int lane16, f32x4 (&acc)[3][3][3]) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -339,11 +352,11 @@ __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 a[2][3][3], b[2][3];
-    conv48_load_step<PITCH>(patch, base, wl, 0, a[0], b[0]);
+    conv48_load_step<PITCH>(patch, base, wr, lane16, 0, a[0], b[0]);
 #pragma unroll
     for (int s = 0; s < 27; ++s) {
         const int cur = s & 1;
-        if (s + 1 < 27) conv48_load_step<PITCH>(patch, base, wl, s + 1, a[cur ^ 1], b[cur ^ 1]);
+        if (s + 1 < 27) conv48_load_step<PITCH>(patch, base, wr, lane16, s + 1, a[cur ^ 1], b[cur ^ 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -379,11 +392,11 @@ constexpr int kG2Dma = (kG2Pieces + 63) / 64;  // wave-wide DMA instructions per
 struct Conv2Tile { const char* src; float* dst; int ty, tx; };
 
 __device__ __forceinline__ void conv2_load_step(const float* buf, const int (&base)[3],
-                                                const f32x4* __restrict__ wl, int g, int kk,
+                                                __amdgpu_buffer_rsrc_t wr, int lane16, int g, int kk,
                                                 f32x4 (&a)[3][3], f32x4 (&b)[3]) {
     const int off = ((kk / 3) * kP2 + (kk % 3)) * 16;
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) b[nt] = wl[((kk * 3 + g) * 3 + nt) * 64];
+    for (int nt = 0; nt < 3; ++nt) b[nt] = load_frag(wr, lane16, g * 3072 + (kk * 9 + nt) * 1024);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -409,7 +422,7 @@ __device__ __forceinline__ void conv2_dma_group(const char* src, float* dst, con
 template <int P>
 __device__ __forceinline__ void conv2_unit(const float* mine, float* other, const char* next_src,
                                            const int (&rel)[kG2Dma], const int (&base)[3],
-                                           const f32x4* __restrict__ wl, int g, int g_next, int lane,
+                                           __amdgpu_buffer_rsrc_t wr, int g, int g_next, int lane,
                                            f32x4 (&a)[2][3][3], f32x4 (&b)[2][3], f32x4 (&acc)[3][3][3]) {
     // everything outstanding was issued at least one step (108 MFMAs) ago
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -425,8 +438,8 @@ __device__ __forceinline__ void conv2_unit(const float* mine, float* other, cons
 #pragma unroll
     for (int kk = 0; kk < 9; ++kk) {
         const int c = (P + kk) & 1;
-        if (kk < 8) conv2_load_step(mine, base, wl, g, kk + 1, a[c ^ 1], b[c ^ 1]);
-        else conv2_load_step(other, base, wl, g_next, 0, a[c ^ 1], b[c ^ 1]);
+        if (kk < 8) conv2_load_step(mine, base, wr, lane * 16, g, kk + 1, a[c ^ 1], b[c ^ 1]);
+        else conv2_load_step(other, base, wr, lane * 16, g_next, 0, a[c ^ 1], b[c ^ 1]);
         // the copy of the next unit's patch goes out behind this step's operand loads, so the wait
         // for those loads (in-order completion) does not have to cover it
         if (kk == 0) conv2_dma_group(next_src, other, rel, lane);
@@ -515,7 +528,7 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
     int base[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * 16 + 4 * kq;
-    const f32x4* wl = reinterpret_cast<const f32x4*>(wfrag) + lane;
+    const __amdgpu_buffer_rsrc_t wr = weight_rsrc(wfrag);
 
     Conv2Tile cur = locate(id);
     int next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
     conv2_dma_group(cur.src, buf0, rel, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x4 a[2][3][3], b[2][3], acc[3][3][3];
-    conv2_load_step(buf0, base, wl, 0, 0, a[0], b[0]);
+    conv2_load_step(buf0, base, wr, lane * 16, 0, 0, a[0], b[0]);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -554,13 +567,13 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
     while (!done) {
         {
             const char* nsrc = g < 2 ? cur.src + (g + 1) * 64 : nxt.src;
-            conv2_unit<0>(buf0, buf1, nsrc, rel, base, wl, g, g < 2 ? g + 1 : 0, lane, a, b, acc);
+            conv2_unit<0>(buf0, buf1, nsrc, rel, base, wr, g, g < 2 ? g + 1 : 0, lane, a, b, acc);
             done = after_unit(buf0);
         }
         if (done) break;
         {
             const char* nsrc = g < 2 ? cur.src + (g + 1) * 64 : nxt.src;
-            conv2_unit<1>(buf1, buf0, nsrc, rel, base, wl, g, g < 2 ? g + 1 : 0, lane, a, b, acc);
+            conv2_unit<1>(buf1, buf0, nsrc, rel, base, wr, g, g < 2 ? g + 1 : 0, lane, a, b, acc);
             done = after_unit(buf1);
         }
     }
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
         f32x4 acc[3][3][3];
         // columns of one lane's 12 may straddle pool rows here, so tile (t, j) of lane-row i uses
         // base[j] for every t and the conv row offset t is applied inside the tile routine
-        conv48_wave_tile<kP3W>(patch, base, reinterpret_cast<const f32x4*>(wfrag) + lane, acc);
+        conv48_wave_tile<kP3W>(patch, base, weight_rsrc(wfrag), lane * 16, acc);
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int c = nt * 16 + ch;

@@ -60,7 +60,7 @@ def gather_streams(cls, maxv, group=None):
     counts = torch.zeros((world,), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
     counts = counts.tolist()
-    cap = max(counts)
+    cap = (max(counts) + 1) // 2 * 2          # even, so every rank's 12*cap-byte slot stays 8-byte aligned
     # one payload per rank: [cap] int64 classes followed by [cap] float32 maxima, as bytes
     pay = torch.zeros((cap * 12,), dtype=torch.uint8, device=dev)
     pay[: n_local * 8] = cls.contiguous().view(torch.uint8)

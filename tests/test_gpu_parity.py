@@ -220,3 +220,126 @@ def test_clip_end_to_end_csv_matches_oracle(engine, oracle_weights, tmp_path, h,
     p = tmp_path / "out.csv"
     seg.write_csv(str(p))
     assert p.read_bytes() == csv
+
+
+# ----------------------------------------------------------------------------- drop-in API / CLI
+def _write_clip(tmp_path, runs, h, w):
+    from cutdet import rawvideo, synth as csynth
+    from oracle import synth
+    cl = csynth.classes_from_runs(runs)
+    frames = synth.clip(SEED, cl, h, w)
+    p = str(tmp_path / "clip.cdraw")
+    rawvideo.write_raw_video(p, frames, fps=30)
+    return p, frames, cl
+
+
+def test_segment_video_cli_1k_frames_320x180(engine, oracle_weights, tmp_path):
+    """The reference's own CPU-runnable configuration: segment_video.py on a 1k-frame 320x180
+    clip.  The CLI's CSV must equal the oracle chain's CSV byte for byte."""
+    import importlib.util
+    from oracle import net as onet
+    from oracle import preprocess, segmentation
+    runs = [(0, 300), (2, 20), (1, 250), (2, 4), (1, 126), (0, 40), (1, 160), (2, 100)]
+    path, frames, cl = _write_clip(tmp_path, runs, 180, 320)
+    assert len(cl) == 1000
+    scores = np.concatenate([onet.forward(oracle_weights, preprocess.preprocess_batch(frames[a:a + 125])).numpy()
+                             for a in range(0, 1000, 125)])
+    _, _, _, want_csv = segmentation.segment_clip(scores)
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cd_segment_video",
+                                                  os.path.join(root, "cut-detection_amd", "segment_video.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(mod.sv_parser.parse_args([path, "--batch-size", "128"]))
+    assert out == os.path.splitext(path)[0] + "_segments.csv"
+    assert open(out, "rb").read() == want_csv
+    # --frame-limit keeps the reference's overshoot rule: limit 300, batch 128 -> 384 frames scored
+    out2 = mod.main(mod.sv_parser.parse_args([path, "--output_path", str(tmp_path / "lim.csv"),
+                                              "--frame-limit", "300", "--batch-size", "128"]))
+    _, _, _, want2 = segmentation.segment_clip(scores[:384])
+    assert open(out2, "rb").read() == want2
+    with pytest.raises(RuntimeError):
+        mod.main(mod.sv_parser.parse_args([path, "--cpu"]))
+
+
+def test_reference_style_driver_loop(engine, oracle_weights, tmp_path):
+    """The reference's loop verbatim in shape: VideoDataset -> DataLoader -> net(batch) -> Segmentation."""
+    from torch.utils.data import DataLoader
+    from frameID.data import VideoDataset
+    from frameID.net import load_default_net
+    from frameID.segmentation import Segmentation
+    from oracle import net as onet
+    from oracle import preprocess, segmentation
+    runs = [(1, 120), (2, 12), (0, 140)]
+    path, frames, cl = _write_clip(tmp_path, runs, 180, 320)
+    ds = VideoDataset(path, resize=256)
+    assert len(ds) == len(cl) and (ds.new_height, ds.new_width) == (144, 256)
+    dl = DataLoader(ds, 50)
+    net, params = load_default_net()
+    net.eval()
+    net.to("cuda:0")
+    yy = []
+    with torch.no_grad():
+        for batch in dl:
+            assert batch.dtype == torch.float32 and tuple(batch.shape[1:]) == (3, 144, 256)
+            batch = batch.to("cuda:0")
+            yy.append(net(batch))
+    yy = torch.cat(yy, 0).to("cpu")
+    want = onet.forward(oracle_weights, preprocess.preprocess_batch(frames)).numpy()
+    assert yy.shape == (len(cl), 3) and np.abs(yy.numpy() - want).max() <= LOGIT_TOL
+    seg = Segmentation(yy)
+    seg.glue_orphans(100, 10)
+    seg.combine_adjacent_segments()
+    _, _, merged, csv = segmentation.segment_clip(want)
+    assert seg.te["start_frames"].tolist() == merged["start_frames"]
+    assert seg.te["frame_types"].tolist() == merged["frame_types"]
+    assert {k: v.dtype for k, v in seg.te.items()} == {
+        "end_frames": torch.int64, "frame_types": torch.int64, "run_lengths": torch.int64,
+        "start_frames": torch.int64, "score_means": torch.float32}
+    p = tmp_path / "o.csv"
+    seg.write_csv(str(p))
+    assert p.read_bytes() == csv
+
+
+def test_segmentation_class_error_cases(engine, golden_dir):
+    from frameID.segmentation import Segmentation
+    cases, arrays = _seg_golden(golden_dir)
+    with pytest.raises(IndexError):
+        Segmentation(torch.zeros((0, 3)))
+    s = Segmentation(torch.from_numpy(arrays["single_short_segment"]))
+    with pytest.raises(IndexError):
+        s.glue_orphans(100, 10)
+    for name in ("many_orphans", "long_clip", "tie_rows"):
+        c = cases[name]
+        s = Segmentation(torch.from_numpy(arrays[name]))
+        s.glue_orphans(*c["thresholds"])
+        s.combine_adjacent_segments()
+        assert s.te["start_frames"].tolist() == c["merged"]["start_frames"]
+        assert s.te["frame_types"].tolist() == c["merged"]["frame_types"]
+        np.testing.assert_allclose(s.te["score_means"].numpy(), _ref_means(c["merged"]), rtol=2e-6)
+
+
+def test_full_size_properties_10k_frames_720p(engine):
+    """BASELINE-size run (batch 256, 720p) checked through size-independent properties: the class
+    stream must equal the generator's labels, segment run lengths must tile the clip, and a second
+    pass over the same frames must reproduce every logit bit (the kernels are deterministic)."""
+    from cutdet import synth as csynth
+    from cutdet.pipeline import ClipClassifier
+    n = 2560
+    runs = csynth.run_table(n, SEED)
+    cl = csynth.classes_from_runs(runs)
+    frames = engine.synth_frames(_classes(engine.device, cl), 720, 1280, SEED)
+    clip = ClipClassifier(engine, n)
+    for a in range(0, n, 256):
+        clip.classify(frames[a:a + 256], a)
+    first = clip.logits.clone()
+    assert clip.cls.cpu().tolist() == cl
+    for a in range(0, n, 256):
+        clip.classify(frames[a:a + 256], a)
+    assert torch.equal(first, clip.logits)
+    res = clip.segment()
+    assert int(res["initial"]["run_lengths"].sum()) == n
+    assert res["initial"]["frame_types"].tolist() == [c for c, _ in runs]
+    assert res["initial"]["run_lengths"].tolist() == [k for _, k in runs]
+    assert int(res["merged"]["run_lengths"].sum()) == n and res["csv"].startswith(b"0,a22\r\n")
