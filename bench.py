@@ -188,6 +188,12 @@ def main():
         conv2_ms = ms / max(1, n_launch)
         achieved = FLOPS_CONV2 * frames_per_launch / (conv2_ms * 1e-3) / 1e12 if n_launch else 0.0
         stages = {k: {"launches": v[0], "ms_total": round(v[1], 3)} for k, v in timing.items() if v[0]}
+        traffic = None      # measured separately under rocprofv3 --pmc; read back if the summary is present
+        try:
+            with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
+                traffic = json.load(f)["conv2_kernel"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         fps = total_frames / dt_max
         out = {
             "metric": "frames/sec classified+segmented, 1280x720 RGB",
@@ -202,7 +208,8 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None, "launch_ms": round(conv2_ms, 4), "flops_per_frame": FLOPS_CONV2,
+                "traffic": traffic, "traffic_unit": "bytes per 256-frame launch (rocprofv3 PMC, profiles/)",
+                "launch_ms": round(conv2_ms, 4), "flops_per_frame": FLOPS_CONV2,
                 "frames_per_launch": round(frames_per_launch, 2),
                 "whole_net_tflops": round(FLOPS_FRAME * fps / world / 1e12, 2),
                 "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
