@@ -321,7 +321,7 @@ def test_segmentation_class_error_cases(engine, golden_dir):
 
 
 def test_full_size_properties_10k_frames_720p(engine):
-    """BASELINE-size run (batch 256, 720p) checked through size-independent properties: the class
+    """Headline-size run (batch 256, 720p) checked through size-independent properties: the class
     stream must equal the generator's labels, segment run lengths must tile the clip, and a second
     pass over the same frames must reproduce every logit bit (the kernels are deterministic)."""
     from cutdet import synth as csynth
