@@ -109,11 +109,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CUTDET_BENCH_BACKEND=gloo + CUTDET_BENCH_ONE_GPU=1 rehearse the multi-rank path on a 1-GPU box
+    backend = os.environ.get("CUTDET_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("CUTDET_BENCH_ONE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from cutdet import api, synth as csynth
     from cutdet.pipeline import ClipClassifier
@@ -174,7 +180,7 @@ def main():
     timing = eng.timing_read()
     eng.timing_enable(False)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())

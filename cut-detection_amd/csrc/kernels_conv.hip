@@ -94,7 +94,7 @@ __device__ __forceinline__ void xcd_frame_tile(int b, int per_frame, int& frame,
 // 4-byte load at any byte address (the hardware handles unaligned global loads)
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
-constexpr int kC1ChunksPerWG = 4;          // consecutive 3-pool-row chunks one workgroup walks
+constexpr int kC1ChunksPerWG = 1;          // consecutive 3-pool-row chunks one workgroup walks
 
 // Staging helpers -------------------------------------------------------------------------
 // Thread t owns LDS column t (network column t-1) for all 11 rows; threads 0..10 also own one
@@ -116,7 +116,11 @@ __device__ __forceinline__ void point_fetch(const uint8_t* __restrict__ fsrc, co
     for (int r = 0; r < kC1Rows; ++r) {
         const int gy = gy0 + r;
         const uint8_t* p = fsrc + (int64_t)sa.sy[min(max(gy, 0), H - 1)] * sa.row_stride + a;
+#ifdef CD_ABL_STAGE
+        raw.v[r] = (xin && gy >= 0 && gy < H && p == nullptr) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
+#else
         raw.v[r] = (xin && gy >= 0 && gy < H) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
+#endif
     }
     {   // column 256 (network column 255), row tid
         const int xo2 = sa.sx[kNetW - 1] * 3, a2 = min(xo2, last);
@@ -174,8 +178,11 @@ __device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__
 // A workgroup walks kC1ChunksPerWG consecutive chunks of one frame.  In MODE 1 the source bytes
 // of chunk k+1 are requested (into registers) before the MFMA work of chunk k starts and are
 // converted and written to LDS after it, so the HBM latency of the gather hides under compute.
+#ifndef CD_C1_LB
+#define CD_C1_LB 4
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256, 4) void conv1_kernel(
+__global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
     int chan_order, const float* __restrict__ lut, const float* __restrict__ wfrag,
     const float* __restrict__ post, float* __restrict__ out, int n, int H, int Hp, int chunks, int groups) {
@@ -239,6 +246,15 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(
             // One 16-channel group at a time: 9 accumulators live instead of 27, which keeps the
             // kernel at 3-4 waves per SIMD so that other waves' MFMAs cover this wave's staging,
             // LDS latency and epilogue.  The A values are re-read from LDS for each group.
+#ifdef CD_C1_AREG
+            float a_all[7][3][3];
+#pragma unroll
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) a_all[s][t][j] = tile[addr[s][j] + t * kC1RS];
+#endif
 #pragma unroll 1
             for (int nt = 0; nt < 3; ++nt) {
                 f32x4 acc[3][3];
@@ -253,7 +269,11 @@ __global__ __launch_bounds__(256, 4) void conv1_kernel(
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
 #pragma unroll
+#ifdef CD_C1_AREG
+                        for (int j = 0; j < 3; ++j) a[t][j] = a_all[s][t][j];
+#else
                         for (int j = 0; j < 3; ++j) a[t][j] = tile[addr[s][j] + t * kC1RS];
+#endif
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
 #pragma unroll

@@ -55,7 +55,10 @@ def gather_streams(cls, maxv, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return cls, maxv
-    dev = cls.device
+    out_dev = cls.device
+    # gloo moves host memory only: stage through the CPU when the group is not RCCL
+    dev = out_dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    cls, maxv = cls.to(dev), maxv.to(dev)
     n_local = cls.shape[0]
     counts = torch.zeros((world,), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
@@ -70,7 +73,7 @@ def gather_streams(cls, maxv, group=None):
     allpay = allpay.view(world, cap * 12)
     out_cls = torch.cat([allpay[r, : counts[r] * 8].view(torch.int64) for r in range(world)])
     out_max = torch.cat([allpay[r, cap * 8: cap * 8 + counts[r] * 4].view(torch.float32) for r in range(world)])
-    return out_cls, out_max
+    return out_cls.to(out_dev), out_max.to(out_dev)
 
 
 class ClipClassifier:
