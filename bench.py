@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--clip-frames", type=int, default=CLIP_FRAMES)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--height", type=int, default=H0, help="source frame height (default: the 720p headline)")
+    ap.add_argument("--width", type=int, default=W0, help="source frame width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batches", type=int, default=10)
     return ap.parse_args()
@@ -131,7 +133,7 @@ def main():
     classes_all = csynth.classes_from_runs(runs)
     first = rank * n_clip
     classes = torch.tensor(classes_all[first:first + n_clip], dtype=torch.uint8, device=dev)
-    frames = eng.synth_frames(classes, H0, W0, SEED, first_index=first)      # [n_clip,720,1280,3] u8 in HBM
+    frames = eng.synth_frames(classes, args.height, args.width, SEED, first_index=first)   # u8 clip in HBM
     eng.reserve(bs, NET_H)
     clip = ClipClassifier(eng, n_clip)
     batches = [(a, min(n_clip, a + bs)) for a in range(0, n_clip, bs)]
@@ -207,7 +209,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{n_clip} synthetic 1280x720 u8 frames per GPU resident in HBM, batch={bs}, "
+            "config": {"workload": f"{n_clip} synthetic {args.width}x{args.height} u8 frames per GPU resident in HBM, batch={bs}, "
                                    "fp32 prod_net, fused resize+classify, GPU run-length encode, host glue/merge, CSV",
                        "frames_per_gpu_timed": frames_done, "segments_out": int(len(merged["start_frames"])),
                        "stitch": "all-gather of (class,max) streams over RCCL" if world > 1 else "none"},

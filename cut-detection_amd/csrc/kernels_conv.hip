@@ -144,17 +144,53 @@ __device__ __forceinline__ void point_commit(float* tile, const float* slut, int
     if (tid < kC1Rows) put_pixel(tile, slut, tid, 256, raw.v[kC1Rows] >> raw.sh_x, bgr);
 }
 
-// MODE 2: general fixed-point bilinear / 2x2 box, straight into LDS.
+// MODE 2: general fixed-point bilinear / 2x2 box.  The two horizontally adjacent source pixels of
+// a tap pair are 6 contiguous bytes, fetched as one unaligned 8-byte load per source row; all 22
+// loads of a column are in flight before the first is used.  Arithmetic as sample_u8().
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+
 __device__ __forceinline__ void generic_stage(float* tile, const float* slut, const uint8_t* __restrict__ fsrc,
                                               const SampleArgs& sa, int gy0, int H, int tid, bool bgr) {
+    const int last = sa.W0 * 3 - 8;            // last byte offset an 8-byte load may start at
     for (int c = tid; c < 257; c += 256) {
         const int gx = c - 1;
+        const bool xin = gx >= 0;
+        const int gxc = max(gx, 0);
+        const int c0 = sa.mode == 2 ? 2 * gxc : sa.sx[gxc];
+        const int a0 = sa.mode == 2 ? 1 : sa.ax[2 * gxc], a1 = sa.mode == 2 ? 1 : sa.ax[2 * gxc + 1];
+        const int start = min(c0 * 3, last);
+        const int sh0 = (c0 * 3 - start) * 8;                  // bit offset of pixel c0 in the 8 bytes
+        const int sh1 = c0 + 1 < sa.W0 ? sh0 + 24 : sh0;       // pixel c0+1 (or c0 again at the border)
+        uint64_t top[kC1Rows], bot[kC1Rows];
+#pragma unroll
+        for (int r = 0; r < kC1Rows; ++r) {
+            const int gy = min(max(gy0 + r, 0), H - 1);
+            int r0, r1;
+            if (sa.mode == 2) { r0 = 2 * gy; r1 = 2 * gy + 1; }
+            else { const int sy = sa.sy[gy]; r0 = min(max(sy, 0), sa.H0 - 1); r1 = min(max(sy + 1, 0), sa.H0 - 1); }
+            top[r] = *reinterpret_cast<const u64_unaligned*>(fsrc + (int64_t)r0 * sa.row_stride + start);
+            bot[r] = *reinterpret_cast<const u64_unaligned*>(fsrc + (int64_t)r1 * sa.row_stride + start);
+        }
+#pragma unroll
         for (int r = 0; r < kC1Rows; ++r) {
             const int gy = gy0 + r;
             uint32_t px = 0;
-            if (gx >= 0 && gy >= 0 && gy < H)
-                px = (uint32_t)sample_u8(fsrc, gy, gx, 0, sa) | ((uint32_t)sample_u8(fsrc, gy, gx, 1, sa) << 8) |
-                     ((uint32_t)sample_u8(fsrc, gy, gx, 2, sa) << 16);
+            if (xin && gy >= 0 && gy < H) {
+                const int b0 = sa.mode == 2 ? 1 : sa.by[2 * gy], b1 = sa.mode == 2 ? 1 : sa.by[2 * gy + 1];
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const int p00 = (int)((top[r] >> (sh0 + 8 * cc)) & 255), p01 = (int)((top[r] >> (sh1 + 8 * cc)) & 255);
+                    const int p10 = (int)((bot[r] >> (sh0 + 8 * cc)) & 255), p11 = (int)((bot[r] >> (sh1 + 8 * cc)) & 255);
+                    int v;
+                    if (sa.mode == 2) v = (p00 + p01 + p10 + p11 + 2) >> 2;
+                    else {
+                        const int S0 = p00 * a0 + p01 * a1, S1 = p10 * a0 + p11 * a1;
+                        v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                        v = min(max(v, 0), 255);
+                    }
+                    px |= (uint32_t)v << (8 * cc);
+                }
+            }
             put_pixel(tile, slut, r, c, px, bgr);
         }
     }
@@ -327,7 +363,7 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
     SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride};
     auto kern = h->rt.mode == 1 ? conv1_kernel<1> : conv1_kernel<2>;
     const int groups = (chunks + kC1ChunksPerWG - 1) / kC1ChunksPerWG;
-    if (W0 < 2) { set_error("cd_forward_u8: source frames must be at least 2 pixels wide"); return CD_EINVAL; }
+    if (W0 < 3) { set_error("cd_forward_u8: source frames must be at least 3 pixels wide"); return CD_EINVAL; }
     hipLaunchKernelGGL(kern, dim3(xcd_grid(n, groups)), dim3(256), 0, s, (const float*)nullptr, src, sa,
                        frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks,
                        groups);
