@@ -22,6 +22,27 @@ constexpr int kPool = 4;        // adaptive average pool output size
 constexpr int kFeat = kC * kPool * kPool;   // 768
 constexpr int kHid = 32;
 constexpr int kOut = 3;
+// block-1 LDS tile: 3 pooled rows of one frame = 255 pool windows = 16 wave tiles
+constexpr int kC1Rows = 11;       // input rows held (3 pooled rows need 9 conv rows + halo)
+constexpr int kC1RS = 272;        // LDS row stride in floats (columns -1 .. 256 used); 272 = 16 mod 32, see c1_tap
+constexpr int kC1PoolRows = 3;
+constexpr int kC1Windows = kC1PoolRows * kW1;   // 255
+constexpr int kP1W = kW1 + 2;     // padded width of the block-1 output in HBM (87)
+constexpr int kP2W = kW2 + 2;     // padded width of the block-2 output in HBM (30)
+// K order of block 1.  The 27 taps (ci, ky, kx) plus one zero-weight pad fill 28 k-slots = 7 MFMA
+// k-steps x 4 (slot k = 4*step + kq).  In an A-operand LDS read the two kq values of a 32-lane group
+// hit the same 16 banks unless their addresses differ by 16 (mod 32) dwords.  With a row stride of
+// 16 (mod 32) floats, taps that differ by one row (ky) or one channel plane (11 rows) do; the slots
+// are therefore filled with such pairs: 9 pairs (ci,0,kx)/(ci,1,kx), 3 pairs (0,2,kx)/(1,2,kx),
+// (2,2,0) with the pad (which reads (2,1,0) with weight 0), and one pair left with a 2-way conflict,
+// (2,2,1)/(2,2,2).  Returns ci*100 + ky*10 + kx, negated-minus-one for the pad.
+constexpr int c1_tap(int k) {
+    const int pair = k >> 1, second = k & 1;
+    if (pair < 9) return (pair % 3) * 100 + second * 10 + pair / 3;            // (ci, 0|1, kx)
+    if (pair < 12) return second * 100 + 20 + (pair - 9);                      // (0|1, 2, kx)
+    if (pair == 12) return second ? -(2 * 100 + 10 + 0) - 1 : 2 * 100 + 20 + 0;  // (2,2,0) + pad at (2,1,0)
+    return 2 * 100 + 20 + 1 + second;                                          // (2,2,1), (2,2,2)
+}
 constexpr int kMaxSrcW = 8192;  // widest source frame the resize tables are sized for
 constexpr int kMaxNetH = 224;   // tallest network input the head kernel's LDS tile holds
 
@@ -36,6 +57,7 @@ struct ResizeTables {
     int* sy;  short* by;   // [h] top sample row (unclamped); [2h] coefficient pairs
     int mode;              // 0 bilinear fixed point, 1 pure point sample, 2 exact 2x2 box
     int H0, W0, h, w;      // geometry the tables currently describe (0 = none)
+    int affine, xm, xa, ym, ya;   // mode 1: sx[x] = xm*x + xa and sy[y] = ym*y + ya hold for every entry
 };
 
 // ---- packed parameters on the device ----------------------------------------------------------
@@ -49,6 +71,7 @@ struct DeviceParams {
     float* fc1w;  // [3][32]
     float* fc1b;  // [3]
     float* lut;   // [256] k/255 in fp32 (correctly rounded division)
+    int* c1tab;   // [16 wave tiles][4][16]: block-1 A-operand bases (3 column groups) and store offsets
 };
 
 }  // namespace cd

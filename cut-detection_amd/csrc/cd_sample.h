@@ -16,6 +16,9 @@ struct SampleArgs {
     int mode;           // 0 bilinear, 1 point sample, 2 exact 2x2 box average
     int H0, W0;
     int64_t row_stride; // bytes
+    // point-sample mode only: when both index tables are affine (sx[x] = xm*x + xa, sy[y] = ym*y + ya;
+    // e.g. 5x+2 for 1280 -> 256) the kernels compute them instead of loading them
+    int affine, xm, xa, ym, ya;
 };
 
 // Resized value (0..255) of output pixel (y, x), memory channel cc, of one source frame.

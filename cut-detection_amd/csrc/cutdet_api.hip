@@ -39,7 +39,7 @@ void bn_affine(const float* g, const float* beta, const float* mu, const float* 
     }
 }
 
-struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut; };
+struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, c1tab; };
 
 // Packs everything the kernels read into one host image; `off` receives where each section
 // starts (in floats) so the caller can rebase them onto the device allocation.
@@ -77,12 +77,13 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     const size_t o_fc1b = section(kOut);
     const size_t o_lut = section(256);
 
-    // block 1 B fragments: lane (kq = lane>>4, col = lane&15) of k-step s holds W[16nt+col][4s+kq]
+    // block 1 B fragments: lane (kq = lane>>4, col = lane&15) of k-step s holds W[16nt+col][tap c1_tap(4s+kq)]
     for (int s = 0; s < 7; ++s)
         for (int nt = 0; nt < 3; ++nt)
             for (int lane = 0; lane < 64; ++lane) {
-                int k = 4 * s + (lane >> 4), oc = 16 * nt + (lane & 15);
-                img[o_w1 + (s * 3 + nt) * 64 + lane] = k < 27 ? cv[0].w[oc * 27 + k] : 0.f;
+                const int tap = c1_tap(4 * s + (lane >> 4)), oc = 16 * nt + (lane & 15);
+                img[o_w1 + (s * 3 + nt) * 64 + lane] =
+                    tap >= 0 ? cv[0].w[oc * 27 + (tap / 100) * 9 + ((tap / 10) % 10) * 3 + tap % 10] : 0.f;
             }
     // blocks 2/3: step (ky, kx, g), k-step e covers input channel 16g + 4kq + e
     for (int l = 1; l < 3; ++l) {
@@ -109,7 +110,24 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     std::memcpy(&img[o_fc1b], fc1b, kOut * sizeof(float));
     for (int k = 0; k < 256; ++k) img[o_lut + k] = (float)k / 255.0f;   // data.py:227 divides, it does not scale
 
-    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut};
+    // Block-1 index tables (what each lane would otherwise compute with integer divisions):
+    //  [wt][j][i]  LDS offset (floats) of the pixel that A-row i of column group j maps to in wave
+    //              tile wt: window W = 16wt + 4(i>>2) + (4j + (i&3))/3, column (4j + (i&3)) % 3
+    //  [wt][3][w]  for window 16wt + w: ((row+1)*87 + col+1)*48 | row, or -1 past the 255th window
+    const size_t o_tab = section(16 * 4 * 16);
+    for (int wt = 0; wt < 16; ++wt)
+        for (int i = 0; i < 16; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                const int c12 = 4 * j + (i & 3);
+                const int W = std::min(16 * wt + 4 * (i >> 2) + c12 / 3, kC1Windows - 1);
+                const int32_t v = (3 * (W / kW1)) * kC1RS + 3 * (W % kW1) + c12 % 3;
+                std::memcpy(&img[o_tab + (wt * 4 + j) * 16 + i], &v, 4);
+            }
+            const int W = 16 * wt + i;
+            const int32_t v = W < kC1Windows ? (((W / kW1 + 1) * kP1W + W % kW1 + 1) * kC) | (W / kW1) : -1;
+            std::memcpy(&img[o_tab + (wt * 4 + 3) * 16 + i], &v, 4);
+        }
+    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_tab};
     return img;
 }
 
@@ -158,6 +176,14 @@ int ensure_tables(cd_handle* h, int H0, int W0, int nh, int nw, hipStream_t s) {
     CD_HIP(hipMemcpy(rt.ax, ax.data(), ax.size() * sizeof(short), hipMemcpyHostToDevice));
     CD_HIP(hipMemcpy(rt.sy, sy.data(), sy.size() * sizeof(int), hipMemcpyHostToDevice));
     CD_HIP(hipMemcpy(rt.by, by.data(), by.size() * sizeof(short), hipMemcpyHostToDevice));
+    rt.affine = 0;
+    if (mode == 1 && nw >= 2 && nh >= 2) {
+        const int xm = sx[1] - sx[0], xa = sx[0], ym = sy[1] - sy[0], ya = sy[0];
+        bool ok = true;
+        for (int x = 0; x < nw; ++x) ok &= sx[x] == xm * x + xa;
+        for (int y = 0; y < nh; ++y) ok &= sy[y] == ym * y + ya;
+        if (ok) { rt.affine = 1; rt.xm = xm; rt.xa = xa; rt.ym = ym; rt.ya = ya; }
+    }
     rt.mode = mode; rt.H0 = H0; rt.W0 = W0; rt.h = nh; rt.w = nw;
     return CD_OK;
 }
@@ -285,6 +311,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->p.w1 = base + off.w1; h->p.w2 = base + off.w2; h->p.w3 = base + off.w3; h->p.post = base + off.post;
     h->p.fc0w = base + off.fc0w; h->p.fc0p = base + off.fc0p; h->p.fc1w = base + off.fc1w;
     h->p.fc1b = base + off.fc1b; h->p.lut = base + off.lut;
+    h->p.c1tab = reinterpret_cast<int*>(base + off.c1tab);
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);
     const size_t t_short = align_up((size_t)2 * kMaxSrcW * sizeof(short), 256);
@@ -409,6 +436,16 @@ int cd_max_argmax(cd_handle* h, const float* scores, int64_t n, int n_classes, f
     DeviceGuard guard(h->device);
     return launch_max_argmax(scores, n, n_classes, maxv, argmax, static_cast<hipStream_t>(stream));
 }
+
+#ifdef CD_DIAG
+// diagnostic builds only: copy bytes out of the block-1 activation workspace
+int cd_debug_peek_act1(cd_handle* h, size_t byte_off, size_t nbytes, void* host_dst) {
+    if (!h || byte_off + nbytes > h->act1_bytes) return CD_EINVAL;
+    CD_HIP(hipDeviceSynchronize());
+    CD_HIP(hipMemcpy(host_dst, reinterpret_cast<char*>(h->act1) + byte_off, nbytes, hipMemcpyDeviceToHost));
+    return CD_OK;
+}
+#endif
 
 int cd_timing_enable(cd_handle* h, int on) {
     if (!h) { set_error("cd_timing_enable: null handle"); return CD_EINVAL; }

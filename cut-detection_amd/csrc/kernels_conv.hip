@@ -58,9 +58,10 @@ __device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3][3], int nt)
     return m;
 }
 
+// 3x3 max of pool window WI over single-group accumulators, seeded with 0: ReLU folded in.
 template <int WI>
 __device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3]) {
-    float m = -INFINITY;
+    float m = 0.f;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -76,13 +77,7 @@ __device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3]) {
 // normalised NCHW tensor (MODE 0) or produced on the fly from the u8 source frame by the
 // fixed-point bilinear resize (MODE 1), so the resized frame never exists in HBM.
 // ------------------------------------------------------------------------------------------
-constexpr int kC1Rows = 11;
-constexpr int kC1RS = 260;                 // LDS row stride (floats); columns -1 .. 256 used
 constexpr int kC1Tile = kInC * kC1Rows * kC1RS;
-constexpr int kC1PoolRows = 3;
-constexpr int kC1Windows = kC1PoolRows * kW1;   // 255
-constexpr int kP1W = kW1 + 2;              // padded width of the block-1 output in HBM (87)
-constexpr int kP2W = kW2 + 2;              // padded width of the block-2 output in HBM (30)
 
 // frame / tile of workgroup b when `per_frame` workgroups make up a frame (XCD-aware order)
 __device__ __forceinline__ void xcd_frame_tile(int b, int per_frame, int& frame, int& tile) {
@@ -109,13 +104,13 @@ __device__ __forceinline__ void point_fetch(const uint8_t* __restrict__ fsrc, co
     const int last = sa.W0 * 3 - 4;            // last byte offset a 4-byte load may start at
     const int gx = tid - 1;
     const bool xin = gx >= 0;
-    const int xo = xin ? sa.sx[gx] * 3 : 0;
+    const int xo = xin ? (sa.affine ? sa.xm * gx + sa.xa : sa.sx[gx]) * 3 : 0;
     const int a = min(xo, last);
     raw.sh = (xo - a) * 8;
 #pragma unroll
     for (int r = 0; r < kC1Rows; ++r) {
-        const int gy = gy0 + r;
-        const uint8_t* p = fsrc + (int64_t)sa.sy[min(max(gy, 0), H - 1)] * sa.row_stride + a;
+        const int gy = gy0 + r, gyc = min(max(gy, 0), H - 1);
+        const uint8_t* p = fsrc + (int64_t)(sa.affine ? sa.ym * gyc + sa.ya : sa.sy[gyc]) * sa.row_stride + a;
 #ifdef CD_ABL_STAGE
         raw.v[r] = (xin && gy >= 0 && gy < H && p == nullptr) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
 #else
@@ -123,10 +118,10 @@ __device__ __forceinline__ void point_fetch(const uint8_t* __restrict__ fsrc, co
 #endif
     }
     {   // column 256 (network column 255), row tid
-        const int xo2 = sa.sx[kNetW - 1] * 3, a2 = min(xo2, last);
+        const int xo2 = (sa.affine ? sa.xm * (kNetW - 1) + sa.xa : sa.sx[kNetW - 1]) * 3, a2 = min(xo2, last);
         raw.sh_x = (xo2 - a2) * 8;
-        const int gy = gy0 + tid;
-        const uint8_t* p = fsrc + (int64_t)sa.sy[min(max(gy, 0), H - 1)] * sa.row_stride + a2;
+        const int gy = gy0 + tid, gyc = min(max(gy, 0), H - 1);
+        const uint8_t* p = fsrc + (int64_t)(sa.affine ? sa.ym * gyc + sa.ya : sa.sy[gyc]) * sa.row_stride + a2;
         raw.v[kC1Rows] = (tid < kC1Rows && gy >= 0 && gy < H) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
     }
 }
@@ -221,10 +216,13 @@ template <int MODE>
 __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
     int chan_order, const float* __restrict__ lut, const float* __restrict__ wfrag,
-    const float* __restrict__ post, float* __restrict__ out, int n, int H, int Hp, int chunks, int groups) {
+    const float* __restrict__ post, const int* __restrict__ tab, float* __restrict__ out, int n, int H, int Hp,
+    int chunks, int groups) {
     __shared__ __attribute__((aligned(16))) float tile[kC1Tile];
-    __shared__ __attribute__((aligned(16))) float stage_out[4][16 * 16];   // per-wave epilogue transpose
-    __shared__ float slut[MODE != 0 ? 256 : 1];
+    // 4 KB shared by two uses that never overlap: the k/255 table while a chunk is staged, then the
+    // per-wave 16x16 transpose buffers of the epilogue (keeps the workgroup under 40 KB: 4 per CU)
+    __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];
+    float* slut = scratch;
     const int tid = threadIdx.x;
     int frame, grp;
     xcd_frame_tile(blockIdx.x, groups, frame, grp);
@@ -235,44 +233,80 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const uint8_t* fsrc = MODE != 0 ? src + (int64_t)frame * frame_stride : nullptr;
     const float* fx = MODE == 0 ? x + (int64_t)frame * kInC * H * kNetW : nullptr;
 
-    if (MODE != 0) slut[tid] = lut[tid];
+#ifdef CD_DIAG
+    // diagnostic build: per-workgroup time stamps go to the slack frame behind the batch
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(out + (int64_t)n * (Hp + 2) * kP1W * kC) + 16 * blockIdx.x;
+    if (tid == 0) {
+        stamps[0] = __builtin_amdgcn_s_memrealtime();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamps[3] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    // The set-up and staging code is short, latency-bound and mostly VALU; the other waves on this
+    // SIMD are issuing MFMAs back to back and, being older, win every arbitration.  Run it at raised
+    // priority and drop back before the MFMA loop.
+    __builtin_amdgcn_s_setprio(3);
+#ifdef CD_DIAG
+    if (tid == 0) stamps[8] = __builtin_amdgcn_s_memrealtime();
+    {
+        volatile int sink = fsrc != nullptr ? fsrc[0] : 0;   // one dependent global byte load
+        (void)sink;
+    }
+    if (tid == 0) stamps[9] = __builtin_amdgcn_s_memrealtime();
+#endif
     PointRaw raw;
     if (MODE == 1) point_fetch(fsrc, sa, 9 * chunk0 - 1, H, tid, raw);
+#ifdef CD_DIAG
+    if (tid == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int wave = tid >> 6, lane = tid & 63;
     const int i = lane & 15, kq = lane >> 4;
     int koff[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
-        int k = min(4 * s + kq, 26);       // k = 27 is padding: its weight is 0, read a valid cell
-        int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
+        int tap = c1_tap(4 * s + kq);      // the pad slot reads a valid cell; its weight is 0
+        if (tap < 0) tap = -tap - 1;
+        const int ci = tap / 100, ky = (tap / 10) % 10, kx = tap % 10;
         koff[s] = (ci * kC1Rows + ky) * kC1RS + kx;
     }
     const int q = lane >> 4, ch = lane & 15;
     float* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
-    float* my_out = stage_out[wave];
-    __syncthreads();                        // slut visible
+    float* my_out = scratch + wave * 256;
 
     for (int kc = 0; kc < nchunks; ++kc) {
         const int py0 = (chunk0 + kc) * kC1PoolRows;
         const int gy0 = 3 * py0 - 1;        // input row held in LDS row 0
-        if (kc > 0) __syncthreads();        // every wave is done reading the previous tile
+        if (kc > 0) { __syncthreads(); __builtin_amdgcn_s_setprio(3); }   // every wave is done with the previous tile
+        if (MODE != 0) { slut[tid] = lut[tid]; __syncthreads(); }
+#ifdef CD_DIAG
+        if (tid == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
         if (MODE == 0) f32_stage(tile, fx, gy0, H, tid);
         else if (MODE == 1) point_commit(tile, slut, tid, raw, bgr);
         else generic_stage(tile, slut, fsrc, sa, gy0, H, tid, bgr);
+#ifdef CD_DIAG
+        if (tid == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
+#endif
         __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+#ifdef CD_DIAG
+        if (tid == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (MODE == 1 && kc + 1 < nchunks) point_fetch(fsrc, sa, gy0 + 9, H, tid, raw);
 
         for (int wt = wave; wt < 16; wt += 4) {
-            const int w0 = wt * 16;
             int base[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                int c12 = 4 * j + (i & 3);
-                int W = min(w0 + 4 * (i >> 2) + c12 / 3, kC1Windows - 1);
-                int wrow = W / kW1, px = W % kW1;
-                base[j] = (3 * wrow) * kC1RS + 3 * px + c12 % 3;
-            }
+            for (int j = 0; j < 3; ++j) base[j] = tab[(wt * 4 + j) * 16 + i];
+            // this lane's piece of the transposed store: window lane>>2, channels 4*(lane&3)..+3
+            const int st = tab[(wt * 4 + 3) * 16 + (lane >> 2)];
+            const bool st_ok = st >= 0 && py0 + (st & 3) < Hp;
+            float* st_ptr = fout + ((int64_t)py0 * kP1W * kC + (st & ~3) + 4 * (lane & 3));
             // A-operand addresses of the 7 k-steps x 3 column groups (conv row t is an immediate)
             int addr[7][3];
 #pragma unroll
@@ -293,11 +327,14 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #endif
 #pragma unroll 1
             for (int nt = 0; nt < 3; ++nt) {
+                // accumulators start from the conv bias (every register of a lane is channel c)
+                const int c = nt * 16 + ch;
+                const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
                 f32x4 acc[3][3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 3; ++j) acc[t][j] = f32x4{bias, bias, bias, bias};
 #pragma unroll
                 for (int s = 0; s < 7; ++s) {
                     const float b = wfrag[(s * 3 + nt) * 64 + lane];
@@ -307,41 +344,46 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #pragma unroll
 #ifdef CD_C1_AREG
                         for (int j = 0; j < 3; ++j) a[t][j] = a_all[s][t][j];
+#elif defined(CD_ABL_AREAD)
+                        for (int j = 0; j < 3; ++j) a[t][j] = __int_as_float(addr[s][j] + t);
 #else
                         for (int j = 0; j < 3; ++j) a[t][j] = tile[addr[s][j] + t * kC1RS];
 #endif
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
 #pragma unroll
+#ifdef CD_ABL_MFMA
+                        for (int j = 0; j < 3; ++j) asm volatile("" :: "v"(a[t][j]), "v"(b));
+#else
                         for (int j = 0; j < 3; ++j) acc[t][j] = mfma4(a[t][j], b, acc[t][j]);
+#endif
                 }
-                // epilogue: lane (q, ch) owns pool windows w0 + 4q .. w0 + 4q + 3 for channel ch + 16 nt.
+                // epilogue: lane (q, ch) owns pool windows 4q .. 4q+3 of the tile for channel ch + 16 nt.
                 // The 16 windows x 16 channels are transposed through 1 KB of LDS so that every lane
                 // stores 16 contiguous bytes (4 channels of one window).
-                const int c = nt * 16 + ch;
-                const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
                 float m[4] = {window_max<0>(acc), window_max<1>(acc), window_max<2>(acc), window_max<3>(acc)};
 #pragma unroll
-                for (int wi = 0; wi < 4; ++wi) my_out[(4 * q + wi) * 16 + ch] = fmaf(fmaxf(m[wi] + bias, 0.f), sc, sh);
+                for (int wi = 0; wi < 4; ++wi) my_out[(4 * q + wi) * 16 + ch] = fmaf(m[wi], sc, sh);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 {
-                    const int win = lane >> 2, c4 = lane & 3;     // window, 4-channel piece
-                    const int W = w0 + win;
-                    const int py = py0 + W / kW1, px = W % kW1;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + win * 16 + 4 * c4);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + (lane >> 2) * 16 + 4 * (lane & 3));
 #ifdef CD_ABL_EPI
-                    if (W < kC1Windows && py < Hp && v[0] == 123456.f)
+                    if (st_ok && v[0] == 123456.f)
 #else
-                    if (W < kC1Windows && py < Hp)
+                    if (st_ok)
 #endif
-                        *reinterpret_cast<f32x4*>(fout + ((int64_t)(py + 1) * kP1W + px + 1) * kC + nt * 16 + 4 * c4) = v;
+                        *reinterpret_cast<f32x4*>(st_ptr + nt * 16) = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read done before the next group rewrites
                 __builtin_amdgcn_wave_barrier();
             }
         }
     }
+#ifdef CD_DIAG
+    __syncthreads();
+    if (tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 static unsigned xcd_grid(int n, int per_frame) { return (unsigned)(((n + 7) / 8) * 8 * per_frame); }
@@ -351,7 +393,7 @@ int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& 
     SampleArgs sa{};
     const int groups = (chunks + kC1ChunksPerWG - 1) / kC1ChunksPerWG;
     hipLaunchKernelGGL(conv1_kernel<0>, dim3(xcd_grid(n, groups)), dim3(256), 0, s, x, (const uint8_t*)nullptr, sa,
-                       (int64_t)0, 0, (const float*)nullptr, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks,
+                       (int64_t)0, 0, (const float*)nullptr, h->p.w1, h->p.post, h->p.c1tab, h->act1, n, g.h, g.h1, chunks,
                        groups);
     CD_HIP(hipGetLastError());
     return CD_OK;
@@ -360,12 +402,13 @@ int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& 
 int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
                     int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s) {
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
-    SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride};
+    SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride,
+                  h->rt.affine, h->rt.xm, h->rt.xa, h->rt.ym, h->rt.ya};
     auto kern = h->rt.mode == 1 ? conv1_kernel<1> : conv1_kernel<2>;
     const int groups = (chunks + kC1ChunksPerWG - 1) / kC1ChunksPerWG;
     if (W0 < 3) { set_error("cd_forward_u8: source frames must be at least 3 pixels wide"); return CD_EINVAL; }
     hipLaunchKernelGGL(kern, dim3(xcd_grid(n, groups)), dim3(256), 0, s, (const float*)nullptr, src, sa,
-                       frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->act1, n, g.h, g.h1, chunks,
+                       frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->p.c1tab, h->act1, n, g.h, g.h1, chunks,
                        groups);
     CD_HIP(hipGetLastError());
     return CD_OK;

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void preprocess_generic_kernel(
 
 int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
                       int64_t frame_stride, int chan_order, float* dst, int nh, int nw, hipStream_t s) {
-    SampleArgs a{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride};
+    SampleArgs a{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride, 0, 0, 0, 0, 0};
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     dim3 grid((unsigned)(n * nh)), block(256);
     if (aligned) {
