@@ -276,6 +276,25 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const int q = lane >> 4, ch = lane & 15;
     float* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
     float* my_out = scratch + wave * 256;
+    // Everything the MFMA loop needs from global memory is fetched once, here, while the tile is
+    // being staged: a load issued inside the loop would cost a full memory round trip (about a
+    // microsecond when the memory pipe is busy with other workgroups' gathers) per 63 MFMAs.
+    float bw[7][3], pbias[3], pscale[3], pshift[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+        for (int s = 0; s < 7; ++s) bw[s][nt] = wfrag[(s * 3 + nt) * 64 + lane];
+        pbias[nt] = post[nt * 16 + ch];
+        pscale[nt] = post[kC + nt * 16 + ch];
+        pshift[nt] = post[2 * kC + nt * 16 + ch];
+    }
+    int tabv[4][4];                          // this wave's four tiles: 3 operand bases + store info
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tabv[k][j] = tab[((wave + 4 * k) * 4 + j) * 16 + i];
+        tabv[k][3] = tab[((wave + 4 * k) * 4 + 3) * 16 + (lane >> 2)];
+    }
 
     for (int kc = 0; kc < nchunks; ++kc) {
         const int py0 = (chunk0 + kc) * kC1PoolRows;
@@ -299,12 +318,13 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #endif
         if (MODE == 1 && kc + 1 < nchunks) point_fetch(fsrc, sa, gy0 + 9, H, tid, raw);
 
-        for (int wt = wave; wt < 16; wt += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {            // wave tile wt = wave + 4k
             int base[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) base[j] = tab[(wt * 4 + j) * 16 + i];
+            for (int j = 0; j < 3; ++j) base[j] = tabv[k][j];
             // this lane's piece of the transposed store: window lane>>2, channels 4*(lane&3)..+3
-            const int st = tab[(wt * 4 + 3) * 16 + (lane >> 2)];
+            const int st = tabv[k][3];
             const bool st_ok = st >= 0 && py0 + (st & 3) < Hp;
             float* st_ptr = fout + ((int64_t)py0 * kP1W * kC + (st & ~3) + 4 * (lane & 3));
             // A-operand addresses of the 7 k-steps x 3 column groups (conv row t is an immediate)
@@ -325,11 +345,10 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #pragma unroll
                     for (int j = 0; j < 3; ++j) a_all[s][t][j] = tile[addr[s][j] + t * kC1RS];
 #endif
-#pragma unroll 1
+#pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
-                // accumulators start from the conv bias (every register of a lane is channel c)
-                const int c = nt * 16 + ch;
-                const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
+                // accumulators start from the conv bias (every register of a lane is one channel)
+                const float bias = pbias[nt], sc = pscale[nt], sh = pshift[nt];
                 f32x4 acc[3][3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
                     for (int j = 0; j < 3; ++j) acc[t][j] = f32x4{bias, bias, bias, bias};
 #pragma unroll
                 for (int s = 0; s < 7; ++s) {
-                    const float b = wfrag[(s * 3 + nt) * 64 + lane];
+                    const float b = bw[s][nt];
                     float a[3][3];
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
