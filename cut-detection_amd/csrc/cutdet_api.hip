@@ -447,6 +447,15 @@ int cd_debug_peek_act1(cd_handle* h, size_t byte_off, size_t nbytes, void* host_
 }
 #endif
 
+#ifdef CD_DIAG
+int cd_debug_peek_act2(cd_handle* h, size_t byte_off, size_t nbytes, void* host_dst) {
+    if (!h || byte_off + nbytes > h->act2_bytes) return CD_EINVAL;
+    CD_HIP(hipDeviceSynchronize());
+    CD_HIP(hipMemcpy(host_dst, reinterpret_cast<char*>(h->act2) + byte_off, nbytes, hipMemcpyDeviceToHost));
+    return CD_OK;
+}
+#endif
+
 int cd_timing_enable(cd_handle* h, int on) {
     if (!h) { set_error("cd_timing_enable: null handle"); return CD_EINVAL; }
     h->timing = on != 0;

@@ -506,6 +506,7 @@ constexpr int kG2Pix = kP2 * kP2;              // 196 pixels
 constexpr int kG2Floats = kG2Pix * 16;         // one channel group of the patch
 constexpr int kG2Pieces = kG2Pix * 4;          // 16-byte pieces per group patch (784)
 constexpr int kG2Dma = (kG2Pieces + 63) / 64;  // wave-wide DMA instructions per group (13)
+constexpr int kG2BufFloats = kG2Dma * 64 * 4;  // LDS buffer, padded to whole DMA instructions
 
 struct Conv2Tile { const char* src; float* dst; int ty, tx; };
 
@@ -523,54 +524,74 @@ __device__ __forceinline__ void conv2_load_step(const float* buf, const int (&ba
 }
 
 // LDS-DMA of one channel group of a patch: 13 wave-wide 16-byte copies, LDS image linear.
+// All 64 lanes take part in the last copy as well (no exec-masked region: a branch here makes the
+// compiler shuttle all 108 accumulators between AGPRs and VGPRs once per unit): its 48 surplus
+// pieces read the first 12 pixels of patch row 14, which exist (next rows of the padded frame or
+// the slack frame), and land in the padding at the end of the LDS buffer.
 __device__ __forceinline__ void conv2_dma_group(const char* src, float* dst, const int (&rel)[kG2Dma], int lane) {
     char* d = reinterpret_cast<char*>(dst);
 #pragma unroll
-    for (int it = 0; it < kG2Dma; ++it) {
-        if (it < kG2Dma - 1 || lane < kG2Pieces - (kG2Dma - 1) * 64)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + rel[it]),
-                                             (__attribute__((address_space(3))) void*)(d + it * 1024), 16, 0, 0);
-    }
+    for (int it = 0; it < kG2Dma; ++it)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)rel[it]),
+                                         (__attribute__((address_space(3))) void*)(d + it * 1024), 16, 0, 0);
 }
 
-// One (tile, channel group) unit: 9 pipelined steps of 108 MFMAs.  P is the parity of the unit
-// in the wave's running sequence: it fixes, at compile time, which LDS buffer the unit reads
-// (`mine`), which one the next unit's patch is copied into (`other`), and which of the two operand
-// register sets holds step 0 (9 steps flip the set, so parities alternate).
-template <int P>
-__device__ __forceinline__ void conv2_unit(const float* mine, float* other, const char* next_src,
+// One (tile, channel group) unit: 9 pipelined steps of 108 MFMAs.  G, the channel group, is a
+// compile-time constant and a tile always starts with operand set 0, so the set each of the 27 steps
+// of a tile reads is fixed at compile time.  Which LDS buffer holds the unit's patch alternates
+// from unit to unit and from tile to tile (a tile is an odd number of units); `mine_off` and
+// `other_off` (floats) select them at run time.  The first MFMA of each accumulator in a tile takes
+// a literal zero as its C operand, so the accumulators are defined and consumed inside one tile
+// body and never cross the loop edge (the compiler otherwise permutes all 108 of them through
+// VGPRs once per unit).
+template <int G>
+__device__ __forceinline__ void conv2_unit(const float* bufs, int mine_off, int other_off, const char* next_src,
                                            const int (&rel)[kG2Dma], const int (&base)[3],
-                                           __amdgpu_buffer_rsrc_t wr, int g, int g_next, int lane,
+                                           __amdgpu_buffer_rsrc_t wr, int lane,
                                            f32x4 (&a)[2][3][3], f32x4 (&b)[2][3], f32x4 (&acc)[3][3][3]) {
     // everything outstanding was issued at least one step (108 MFMAs) ago
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // Pin step 0's operands in their registers: left to itself the compiler re-loads the weights
-    // here instead of carrying them across the loop edge, and the wait for that re-load would also
-    // wait (VMEM completes in order) for the patch copy issued below.
+    int bm[3], bo[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(a[P][t][j]));
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt) asm volatile("" : "+v"(b[P][nt]));
+    for (int j = 0; j < 3; ++j) { bm[j] = base[j] + mine_off; bo[j] = base[j] + other_off; }
 #pragma unroll
     for (int kk = 0; kk < 9; ++kk) {
-        const int c = (P + kk) & 1;
-        if (kk < 8) conv2_load_step(mine, base, wr, lane * 16, g, kk + 1, a[c ^ 1], b[c ^ 1]);
-        else conv2_load_step(other, base, wr, lane * 16, g_next, 0, a[c ^ 1], b[c ^ 1]);
-        // the copy of the next unit's patch goes out behind this step's operand loads, so the wait
-        // for those loads (in-order completion) does not have to cover it
-        if (kk == 0) conv2_dma_group(next_src, other, rel, lane);
-        __builtin_amdgcn_sched_barrier(0);
+        constexpr int kFirst = G * 9;
+        const int c = (kFirst + kk) & 1;
+        // Next step's operands: from this unit's patch, or (last step) from the next unit's
+        const int* ab = kk < 8 ? bm : bo;
+        const int ng = kk < 8 ? G : (G + 1) % 3, nk = kk < 8 ? kk + 1 : 0;
+        const int off = ((nk / 3) * kP2 + (nk % 3)) * 16;
+        // The wave is alone on its SIMD, so whatever it issues between two MFMAs that takes longer
+        // than the 32-cycle MFMA leaves the matrix pipe idle.  The step's memory instructions are
+        // therefore dealt out one per MFMA instead of going out as a block: 3 weight loads, 9 LDS
+        // reads and, in step 0, the 13 copies of the next unit's patch (behind the operand loads,
+        // so that the wait for those - VMEM completes in order - does not have to cover the copies).
+        const int n_side = kk == 0 ? 12 + kG2Dma : 12;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int nt = 0; nt < 3; ++nt)
-                        acc[t][j][nt] = mfma4(a[c][t][j][e], b[c][nt][e], acc[t][j][nt]);
+        for (int m = 0; m < 108; ++m) {
+            const int e = m / 27, t = (m / 9) % 3, j = (m / 3) % 3, nt = m % 3;
+            if (G == 0 && kk == 0 && e == 0)
+                acc[t][j][nt] = mfma4(a[c][t][j][e], b[c][nt][e], f32x4{0.f, 0.f, 0.f, 0.f});
+            else
+                acc[t][j][nt] = mfma4(a[c][t][j][e], b[c][nt][e], acc[t][j][nt]);
+            if (m < n_side) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < 3) {
+                    b[c ^ 1][m] = load_frag(wr, lane * 16, ng * 3072 + (nk * 9 + m) * 1024);
+                } else if (m < 12) {
+                    const int lt = (m - 3) / 3, lj = (m - 3) % 3;
+                    a[c ^ 1][lt][lj] = *reinterpret_cast<const f32x4*>(bufs + ab[lj] + off + lt * kP2 * 16);
+                } else {
+                    const int it = m - 12;
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(next_src + (uint32_t)rel[it]),
+                        (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(const_cast<float*>(bufs) + other_off) + it * 1024),
+                        16, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -578,7 +599,7 @@ __device__ __forceinline__ void conv2_unit(const float* mine, float* other, cons
 // pooled + normalised results of one wave tile -> HBM, transposed through `scratch` (3 KB of an
 // idle patch buffer) so that each pool window's 48 channels leave as 16-byte stores
 __device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc)[3][3][3],
-                                               const float* __restrict__ post, const Conv2Tile& t, int Hp,
+                                               const float* post, const Conv2Tile& t, int Hp,
                                                int lane) {
     const int q = lane >> 4, ch = lane & 15;
 #pragma unroll
@@ -609,8 +630,8 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
                                                    const float* __restrict__ wfrag,
                                                    const float* __restrict__ post, int n, int Hin, int Hp,
                                                    int tiles_x, int tiles_y, int total_tiles) {
-    __shared__ __attribute__((aligned(16))) float buf0[kG2Floats];
-    __shared__ __attribute__((aligned(16))) float buf1[kG2Floats];
+    __shared__ __attribute__((aligned(16))) float bufs[2 * kG2BufFloats];
+    __shared__ float spost[3 * kC];               // bias / BN scale / BN shift: read by every epilogue
     const int lane = threadIdx.x;
     const int per_frame = tiles_x * tiles_y;
     const int64_t in_frame = (int64_t)(Hin + 2) * kP1W * kC * 4, out_frame = (int64_t)(Hp + 2) * kP2W * kC;
@@ -648,52 +669,66 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
     for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * 16 + 4 * kq;
     const __amdgpu_buffer_rsrc_t wr = weight_rsrc(wfrag);
 
+#ifdef CD_DIAG
+    // diagnostic build: time stamps of the first 400 waves go to the slack frame behind the batch
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(out + (int64_t)n * out_frame) + 32 * blockIdx.x;
+    int nstamp = 0;
+#define CD_STAMP() do { if (lane == 0 && nstamp < 32 && blockIdx.x < 400) stamps[nstamp] = __builtin_amdgcn_s_memrealtime(); ++nstamp; } while (0)
+#else
+#define CD_STAMP() do { } while (0)
+#endif
+    CD_STAMP();
     Conv2Tile cur = locate(id);
     int next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
     Conv2Tile nxt = locate(next_id);
-    conv2_dma_group(cur.src, buf0, rel, lane);
+    conv2_dma_group(cur.src, bufs, rel, lane);
+    spost[lane] = post[lane];
+    spost[64 + lane] = post[64 + lane];
+    if (lane < 3 * kC - 128) spost[128 + lane] = post[128 + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x4 a[2][3][3], b[2][3], acc[3][3][3];
-    conv2_load_step(buf0, base, wr, lane * 16, 0, 0, a[0], b[0]);
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv2_load_step(bufs, base, wr, lane * 16, 0, 0, a[0], b[0]);
+    CD_STAMP();
 
-    // Units alternate parity; a tile is three units, so tile boundaries fall on either parity.
-    int g = 0;
-    bool done = false;
-    auto after_unit = [&](float* scratch) {      // returns true when the wave has no more tiles
-        if (g < 2) { ++g; return false; }
-        conv2_epilogue(scratch, acc, post, cur, Hp, lane);
-        if (next_id < 0) return true;
+    // One loop iteration = one wave tile = three units.  `first` is the buffer (as a float offset)
+    // that holds group 0 of the current tile; the look-ahead copy in the last unit puts group 0 of
+    // the next tile into the other one.
+    int first = 0;
+    for (;;) {
+        const int second = kG2BufFloats - first;
+        // Pin step 0's operands in their registers: left to itself the compiler re-loads the
+        // weights here instead of carrying them across the loop edge, and the wait for that
+        // re-load would also wait (VMEM completes in order) for the patch copy issued below.
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(a[0][t][j]));
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) asm volatile("" : "+v"(b[0][nt]));
+        conv2_unit<0>(bufs, first, second, cur.src + 64, rel, base, wr, lane, a, b, acc);
+        CD_STAMP();
+        conv2_unit<1>(bufs, second, first, cur.src + 128, rel, base, wr, lane, a, b, acc);
+        CD_STAMP();
+        conv2_unit<2>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc);
+        CD_STAMP();
+        // `first` was last read one step ago; the next tile's first unit copies into it only after
+        // the epilogue's final LDS wait
+        conv2_epilogue(bufs + first, acc, spost, cur, Hp, lane);
+        CD_STAMP();
+        if (next_id < 0) break;
         id = next_id;
         cur = nxt;
         next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
         nxt = locate(next_id);
-        g = 0;
+        first = second;
+        // 27 steps leave the next step's operands in set 1; a tile starts from set 0
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j) a[0][t][j] = a[1][t][j];
 #pragma unroll
-                for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        return false;
-    };
-    while (!done) {
-        {
-            const char* nsrc = g < 2 ? cur.src + (g + 1) * 64 : nxt.src;
-            conv2_unit<0>(buf0, buf1, nsrc, rel, base, wr, g, g < 2 ? g + 1 : 0, lane, a, b, acc);
-            done = after_unit(buf0);
-        }
-        if (done) break;
-        {
-            const char* nsrc = g < 2 ? cur.src + (g + 1) * 64 : nxt.src;
-            conv2_unit<1>(buf1, buf0, nsrc, rel, base, wr, g, g < 2 ? g + 1 : 0, lane, a, b, acc);
-            done = after_unit(buf1);
-        }
+        for (int nt = 0; nt < 3; ++nt) b[0][nt] = b[1][nt];
     }
     // the look-ahead copy and operand loads of a unit that will never run are still in flight
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
