@@ -44,12 +44,17 @@ constexpr int c1_tap(int k) {
     return 2 * 100 + 20 + 1 + second;                                          // (2,2,1), (2,2,2)
 }
 constexpr int kMaxSrcW = 8192;  // widest source frame the resize tables are sized for
-constexpr int kMaxNetH = 224;   // tallest network input the head kernel's LDS tile holds
+constexpr int kMaxNetH = 215;   // tallest network input whose block-2 activation fits the head kernel's LDS
+constexpr int kLdsBytes = 160 * 1024;
 
 struct Geometry {               // per network-input height
     int h, h1, h2, h3;          // input rows, rows after each conv block
 };
 inline Geometry geometry(int h) { Geometry g; g.h = h; g.h1 = h / 3; g.h2 = g.h1 / 3; g.h3 = g.h2 / 3; return g; }
+// LDS of the block-3 + head kernel: padded block-2 frame, pooled block-3 tensor, features, hidden units
+inline size_t head_lds_bytes(const Geometry& g) {
+    return sizeof(float) * ((size_t)(g.h2 + 2) * (kW2 + 2) * kC + (size_t)g.h3 * kW3 * kC + kFeat + kHid);
+}
 
 // ---- resize tables (device) -------------------------------------------------------------------
 struct ResizeTables {
@@ -114,6 +119,7 @@ int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& 
 int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
                     int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s);
 int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s);
+int init_conv3_head();
 int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logits, float* maxv,
                       int64_t* argmax, hipStream_t s);
 int launch_rle(const cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset,

@@ -220,7 +220,7 @@ int check_net_shape(int n, int net_h, int net_w, Geometry* g) {
     if (n < 1) { set_error("batch of %d frames", n); return CD_EINVAL; }
     if (net_w != kNetW) { set_error("network input width must be %d, got %d", kNetW, net_w); return CD_EINVAL; }
     *g = geometry(net_h);
-    if (g->h3 < 1 || net_h > kMaxNetH) {
+    if (g->h3 < 1 || net_h > kMaxNetH || head_lds_bytes(*g) > (size_t)kLdsBytes) {
         set_error("network input height %d unsupported (27..%d rows)", net_h, kMaxNetH);
         return CD_EINVAL;
     }
@@ -324,6 +324,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->rle_blocks_cap = 1 << 16;   // x 4096 frames per block
     CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->rle_blocks), (size_t)h->rle_blocks_cap * sizeof(int64_t)));
 #undef CD_TRY
+    if (init_conv3_head() != CD_OK) return fail(CD_EHIP);
     *out = h;
     return CD_OK;
 }

@@ -463,28 +463,34 @@ __device__ __forceinline__ void conv48_load_step(const float* patch, const int (
 template <int PITCH>
 __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (&base)[3],
                                                  __amdgpu_buffer_rsrc_t wr, int lane16, f32x4 (&acc)[3][3][3]) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt) acc[t][j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 a[2][3][3], b[2][3];
     conv48_load_step<PITCH>(patch, base, wr, lane16, 0, a[0], b[0]);
 #pragma unroll
     for (int s = 0; s < 27; ++s) {
         const int cur = s & 1;
-        if (s + 1 < 27) conv48_load_step<PITCH>(patch, base, wr, lane16, s + 1, a[cur ^ 1], b[cur ^ 1]);
-        __builtin_amdgcn_sched_barrier(0);
+        const int nk = (s + 1) / 3, ng = (s + 1) % 3;
+        const int off = ((nk / 3) * PITCH + (nk % 3)) * kC + 16 * ng;
+        // next step's 3 weight loads and 9 LDS reads go out one per MFMA: with one wave per SIMD,
+        // anything issued as a block between two MFMAs leaves the matrix pipe idle
+        const int n_side = s + 1 < 27 ? 12 : 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int nt = 0; nt < 3; ++nt)
-                        acc[t][j][nt] = mfma4(a[cur][t][j][e], b[cur][nt][e], acc[t][j][nt]);
+        for (int m = 0; m < 108; ++m) {
+            const int e = m / 27, t = (m / 9) % 3, j = (m / 3) % 3, nt = m % 3;
+            if (s == 0 && e == 0)
+                acc[t][j][nt] = mfma4(a[cur][t][j][e], b[cur][nt][e], f32x4{0.f, 0.f, 0.f, 0.f});
+            else
+                acc[t][j][nt] = mfma4(a[cur][t][j][e], b[cur][nt][e], acc[t][j][nt]);
+            if (m < n_side) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < 3) {
+                    b[cur ^ 1][m] = load_frag(wr, lane16, ((s + 1) * 3 + m) * 1024);
+                } else {
+                    const int lt = (m - 3) / 3, lj = (m - 3) % 3;
+                    a[cur ^ 1][lt][lj] = *reinterpret_cast<const f32x4*>(patch + base[lj] + off + lt * PITCH * kC);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -767,6 +773,19 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     float* hid = feat + kFeat;                            // [32]
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int q = lane >> 4, ch = lane & 15;
+
+#ifdef CD_DIAG
+    // diagnostic build: per-wave time stamps go to the slack frame behind the batch's activations
+    unsigned long long* st3 = reinterpret_cast<unsigned long long*>(const_cast<float*>(in) + (int64_t)gridDim.x * (Hin + 2) * kP3W * kC) + (blockIdx.x * 4 + wave) * 8;
+    int nst3 = 0;
+#define CD_STAMP3() do { if (lane == 0 && blockIdx.x < 400) st3[nst3] = __builtin_amdgcn_s_memrealtime(); ++nst3; } while (0)
+#else
+#define CD_STAMP3() do { } while (0)
+#endif
+    CD_STAMP3();
     // the padded block-2 activation of this frame is contiguous in HBM: a linear LDS-DMA copy
     const char* fin = reinterpret_cast<const char*>(in + (int64_t)frame * (Hin + 2) * kP3W * kC);
     const int patch_bytes = (Hin + 2) * kP3W * kC * 4;
@@ -778,19 +797,38 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    CD_STAMP3();
+    // Everything else that does not depend on the activations is requested now and lands while the
+    // convolution runs: a dependent global load costs more than a microsecond here, and the head
+    // would otherwise pay that once per layer.  A thread's 96 weights of Linear(768,32) (8 threads
+    // per output) stay in registers through the convolution.
+    const int fo = tid >> 3, part = tid & 7;
+    f32x4 w0[24];
+    {
+        // 16-byte piece k*8 + part of the output's weight row: the 8 threads of an output read 128
+        // contiguous bytes per load
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(fc0w + fo * kFeat) + part;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) w0[k] = wrow[k * 8];
+    }
+    const float h_bias = fc0p[fo], h_scale = fc0p[kHid + fo], h_shift = fc0p[2 * kHid + fo];
+    float pbias[3], pscale[3], pshift[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        pbias[nt] = post[nt * 16 + ch]; pscale[nt] = post[kC + nt * 16 + ch]; pshift[nt] = post[2 * kC + nt * 16 + ch];
+    }
+    const float l_w01 = fc1w[min(tid >> 5, 1) * kHid + (tid & 31)], l_w2 = fc1w[2 * kHid + (tid & 31)];
+    const float l_b0 = fc1b[0], l_b1 = fc1b[1], l_b2 = fc1b[2];
 
-    const int wave = tid >> 6, lane = tid & 63;
-    const int i = lane & 15, kq = lane >> 4;
-    const int q = lane >> 4, ch = lane & 15;
     const int windows = Hp * kW3;
     const int wave_tiles = (windows + 15) / 16;
     for (int wt = wave; wt < wave_tiles; wt += 4) {
-        const int w0 = wt * 16;
+        const int w0i = wt * 16;
         int base[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             int c12 = 4 * j + (i & 3);
-            int W = min(w0 + 4 * (i >> 2) + c12 / 3, windows - 1);
+            int W = min(w0i + 4 * (i >> 2) + c12 / 3, windows - 1);
             int wrow = W / kW3, px = W % kW3;
             base[j] = ((3 * wrow) * kP3W + 3 * px + c12 % 3) * kC + 4 * kq;
         }
@@ -798,20 +836,23 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
         // columns of one lane's 12 may straddle pool rows here, so tile (t, j) of lane-row i uses
         // base[j] for every t and the conv row offset t is applied inside the tile routine
         conv48_wave_tile<kP3W>(patch, base, weight_rsrc(wfrag), lane * 16, acc);
+        CD_STAMP3();
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int c = nt * 16 + ch;
-            const float bias = post[c], sc = post[kC + c], sh = post[2 * kC + c];
             float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
                           window_max<3>(acc, nt)};
 #pragma unroll
             for (int wi = 0; wi < 4; ++wi) {
-                int W = w0 + 4 * q + wi;
-                if (W < windows) pooled[W * kC + c] = fmaf(fmaxf(m[wi] + bias, 0.f), sc, sh);
+                int W = w0i + 4 * q + wi;
+                if (W < windows) pooled[W * kC + c] = fmaf(fmaxf(m[wi] + pbias[nt], 0.f), pscale[nt], pshift[nt]);
             }
         }
     }
+    if (wave == 3) CD_STAMP3();
+    CD_STAMP3();
     __syncthreads();
+    CD_STAMP3();
 
     // adaptive average pool + flatten: feat[c*16 + bi*4 + bj]
     for (int o = tid; o < kFeat; o += 256) {
@@ -824,56 +865,61 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
         feat[o] = sum / (float)((ye - ys) * (xe - xs));
     }
     __syncthreads();
+    CD_STAMP3();
 
-    // Linear(768, 32): 8 lanes per output, 96 inputs each, then a 3-step butterfly
+    // Linear(768, 32): 8 lanes per output, 96 inputs each (interleaved by 16-byte pieces), then a
+    // 3-step butterfly
     {
-        const int o = tid >> 3, part = tid & 7;
-        const f32x4* wrow = reinterpret_cast<const f32x4*>(fc0w + o * kFeat + part * 96);
-        const f32x4* frow = reinterpret_cast<const f32x4*>(feat + part * 96);
+        const f32x4* frow = reinterpret_cast<const f32x4*>(feat) + part;
         float sum = 0.f;
-#pragma unroll 4
+#pragma unroll
         for (int k = 0; k < 24; ++k) {
-            f32x4 w = wrow[k], f = frow[k];
+            const f32x4 w = w0[k], f = frow[k * 8];
             sum = fmaf(w[0], f[0], sum); sum = fmaf(w[1], f[1], sum);
             sum = fmaf(w[2], f[2], sum); sum = fmaf(w[3], f[3], sum);
         }
         sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-        if (part == 0) {
-            float v = fmaxf(sum + fc0p[o], 0.f);
-            hid[o] = fmaf(v, fc0p[kHid + o], fc0p[2 * kHid + o]);
-        }
+        if (part == 0) hid[fo] = fmaf(fmaxf(sum + h_bias, 0.f), h_scale, h_shift);
     }
     __syncthreads();
-    if (tid == 0) {
-        float l[kOut];
-        for (int o = 0; o < kOut; ++o) {
-            float sum = 0.f;
-            for (int k = 0; k < kHid; ++k) sum = fmaf(fc1w[o * kHid + k], hid[k], sum);
-            l[o] = sum + fc1b[o];
-            logits[(int64_t)frame * kOut + o] = l[o];
+    // Linear(32, 3): one 32-lane group per output, product per lane, 5-step butterfly; then
+    // torch.max semantics: first maximum wins; a NaN wins over everything (first NaN)
+    if (tid < 64) {
+        const int k = tid & 31;                    // lanes 0-31: output 0, lanes 32-63: output 1
+        float p0 = l_w01 * hid[k];
+        float p2 = l_w2 * hid[k];                  // output 2, computed by both halves
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) { p0 += __shfl_xor(p0, d); p2 += __shfl_xor(p2, d); }
+        const float l0 = __shfl(p0, 0) + l_b0, l1 = __shfl(p0, 32) + l_b1, l2 = p2 + l_b2;
+        if (tid == 0) {
+            const float l[kOut] = {l0, l1, l2};
+            float best = l[0];
+            int bi = 0;
+            for (int o2 = 0; o2 < kOut; ++o2) {
+                logits[(int64_t)frame * kOut + o2] = l[o2];
+                if (o2 > 0 && !(best != best) && (l[o2] > best || l[o2] != l[o2])) { best = l[o2]; bi = o2; }
+            }
+            if (maxv) maxv[frame] = best;
+            if (argmax) argmax[frame] = bi;
         }
-        // torch.max semantics: first maximum wins; a NaN wins over everything (first NaN)
-        float best = l[0];
-        int bi = 0;
-        for (int o = 1; o < kOut; ++o)
-            if (!(best != best) && (l[o] > best || l[o] != l[o])) { best = l[o]; bi = o; }
-        if (maxv) maxv[frame] = best;
-        if (argmax) argmax[frame] = bi;
     }
+    CD_STAMP3();
+}
+
+// The head kernel needs more dynamic LDS than the default limit; the limit is a per-device
+// attribute of the kernel, so this runs once per handle with the handle's device current.
+int init_conv3_head() {
+    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    return CD_OK;
 }
 
 int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logits, float* maxv,
                       int64_t* argmax, hipStream_t s) {
-    const size_t lds = sizeof(float) * ((size_t)(g.h2 + 2) * kP3W * kC + (size_t)g.h3 * kW3 * kC + kFeat + kHid);
-    if (lds > 160 * 1024) {
-        set_error("network input of %d rows needs %zu bytes of LDS in the head kernel (max 163840)", g.h, lds);
+    const size_t lds = head_lds_bytes(g);
+    if (lds > (size_t)kLdsBytes) {
+        set_error("network input of %d rows needs %zu bytes of LDS in the head kernel (max %d)", g.h, lds, kLdsBytes);
         return CD_EINVAL;
-    }
-    static bool attr_set = false;   // raise the dynamic-LDS limit once per process
-    if (!attr_set) {
-        CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     hipLaunchKernelGGL(conv3_head_kernel, dim3((unsigned)n), dim3(256), lds, s, h->act2, h->p.w3,
                        h->p.post + 6 * kC, h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax,
