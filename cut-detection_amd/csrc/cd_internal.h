@@ -76,7 +76,6 @@ struct DeviceParams {
     float* fc1w;  // [3][32]
     float* fc1b;  // [3]
     float* lut;   // [256] k/255 in fp32 (correctly rounded division)
-    int* c1tab;   // [16 wave tiles][4][16]: block-1 A-operand bases (3 column groups) and store offsets
 };
 
 }  // namespace cd

@@ -39,7 +39,7 @@ void bn_affine(const float* g, const float* beta, const float* mu, const float* 
     }
 }
 
-struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, c1tab; };
+struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut; };
 
 // Packs everything the kernels read into one host image; `off` receives where each section
 // starts (in floats) so the caller can rebase them onto the device allocation.
@@ -67,7 +67,7 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
 
     std::vector<float> img;
     auto section = [&](size_t n) { size_t at = align_up(img.size(), 64); img.resize(at + n, 0.f); return at; };
-    const size_t o_w1 = section(7 * 3 * 64);
+    const size_t o_w1 = section(9 * 64 * 4);
     const size_t o_w2 = section(27 * 3 * 64 * 4);
     const size_t o_w3 = section(27 * 3 * 64 * 4);
     const size_t o_post = section(3 * 3 * kC);
@@ -77,12 +77,15 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     const size_t o_fc1b = section(kOut);
     const size_t o_lut = section(256);
 
-    // block 1 B fragments: lane (kq = lane>>4, col = lane&15) of k-step s holds W[16nt+col][tap c1_tap(4s+kq)]
+    // Block 1, everything a lane keeps in registers, as nine 16-byte pieces [piece][lane][4] (a wave
+    // reads one contiguous KB per piece).  Pieces 2nt, 2nt+1: B fragments of k-steps 0-3 and 4-6 of
+    // channel group nt; lane (kq = lane>>4, col = lane&15) of k-step s holds W[16nt+col][tap c1_tap(4s+kq)].
+    // Pieces 6+nt are filled in below with {bias, BN scale, BN shift, 0} of channel 16nt + col.
     for (int s = 0; s < 7; ++s)
         for (int nt = 0; nt < 3; ++nt)
             for (int lane = 0; lane < 64; ++lane) {
                 const int tap = c1_tap(4 * s + (lane >> 4)), oc = 16 * nt + (lane & 15);
-                img[o_w1 + (s * 3 + nt) * 64 + lane] =
+                img[o_w1 + ((2 * nt + s / 4) * 64 + lane) * 4 + s % 4] =
                     tap >= 0 ? cv[0].w[oc * 27 + (tap / 100) * 9 + ((tap / 10) % 10) * 3 + tap % 10] : 0.f;
             }
     // blocks 2/3: step (ky, kx, g), k-step e covers input channel 16g + 4kq + e
@@ -103,6 +106,12 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
         std::memcpy(p, cv[l].b, kC * sizeof(float));
         bn_affine(cv[l].g, cv[l].beta, cv[l].mu, cv[l].var, kC, p + kC, p + 2 * kC);
     }
+    for (int nt = 0; nt < 3; ++nt)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int c = 16 * nt + (lane & 15);
+            float* d = &img[o_w1 + ((6 + nt) * 64 + lane) * 4];
+            d[0] = img[o_post + c]; d[1] = img[o_post + kC + c]; d[2] = img[o_post + 2 * kC + c];
+        }
     std::memcpy(&img[o_fc0w], fc0w, (size_t)kHid * kFeat * sizeof(float));
     std::memcpy(&img[o_fc0p], fc0b, kHid * sizeof(float));
     bn_affine(fc0g, fc0beta, fc0mu, fc0var, kHid, &img[o_fc0p + kHid], &img[o_fc0p + 2 * kHid]);
@@ -110,24 +119,7 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     std::memcpy(&img[o_fc1b], fc1b, kOut * sizeof(float));
     for (int k = 0; k < 256; ++k) img[o_lut + k] = (float)k / 255.0f;   // data.py:227 divides, it does not scale
 
-    // Block-1 index tables (what each lane would otherwise compute with integer divisions):
-    //  [wt][j][i]  LDS offset (floats) of the pixel that A-row i of column group j maps to in wave
-    //              tile wt: window W = 16wt + 4(i>>2) + (4j + (i&3))/3, column (4j + (i&3)) % 3
-    //  [wt][3][w]  for window 16wt + w: ((row+1)*87 + col+1)*48 | row, or -1 past the 255th window
-    const size_t o_tab = section(16 * 4 * 16);
-    for (int wt = 0; wt < 16; ++wt)
-        for (int i = 0; i < 16; ++i) {
-            for (int j = 0; j < 3; ++j) {
-                const int c12 = 4 * j + (i & 3);
-                const int W = std::min(16 * wt + 4 * (i >> 2) + c12 / 3, kC1Windows - 1);
-                const int32_t v = (3 * (W / kW1)) * kC1RS + 3 * (W % kW1) + c12 % 3;
-                std::memcpy(&img[o_tab + (wt * 4 + j) * 16 + i], &v, 4);
-            }
-            const int W = 16 * wt + i;
-            const int32_t v = W < kC1Windows ? (((W / kW1 + 1) * kP1W + W % kW1 + 1) * kC) | (W / kW1) : -1;
-            std::memcpy(&img[o_tab + (wt * 4 + 3) * 16 + i], &v, 4);
-        }
-    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_tab};
+    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut};
     return img;
 }
 
@@ -311,7 +303,6 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->p.w1 = base + off.w1; h->p.w2 = base + off.w2; h->p.w3 = base + off.w3; h->p.post = base + off.post;
     h->p.fc0w = base + off.fc0w; h->p.fc0p = base + off.fc0p; h->p.fc1w = base + off.fc1w;
     h->p.fc1b = base + off.fc1b; h->p.lut = base + off.lut;
-    h->p.c1tab = reinterpret_cast<int*>(base + off.c1tab);
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);
     const size_t t_short = align_up((size_t)2 * kMaxSrcW * sizeof(short), 256);

@@ -89,54 +89,78 @@ __device__ __forceinline__ void xcd_frame_tile(int b, int per_frame, int& frame,
 // 4-byte load at any byte address (the hardware handles unaligned global loads)
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
-constexpr int kC1ChunksPerWG = 1;          // consecutive 3-pool-row chunks one workgroup walks
+#ifndef CD_C1_CPW
+#define CD_C1_CPW 1
+#endif
+constexpr int kC1MaxChunksPerWG = CD_C1_CPW;   // consecutive 3-pool-row chunks one workgroup walks
+
+// Correctly rounded k / 255 for k = 0..255 without a table: one Newton correction of k * (1/255)
+// (checked exhaustively against the division data.py:227 performs).
+__device__ __forceinline__ float byte_to_unit(float k) {
+    const float r = 1.0f / 255.0f;
+    const float q = k * r;
+    return fmaf(fmaf(-255.0f, q, k), r, q);
+}
 
 // Staging helpers -------------------------------------------------------------------------
 // Thread t owns LDS column t (network column t-1) for all 11 rows; threads 0..10 also own one
 // cell of column 256 (row = t).
 
 // MODE 1 fetch: one unaligned dword per cell (its low 3 bytes, after a shift, are the pixel).
-// Nothing here waits for the loads: the values are first touched in point_commit().
-struct PointRaw { uint32_t v[kC1Rows + 1]; int sh, sh_x; };
+// Nothing here waits for a load: the values are first touched in point_commit().  Piece u of a
+// chunk is row u of the thread's column (u < 11) or the thread's cell of column 256 (u = 11), so
+// that a chunk's fetch can be dealt out over the 12 (wave tile, channel group) units of the
+// previous chunk's MFMA work.
+struct PointRaw { uint32_t v[kC1Rows + 1]; };
+struct PointCol { int a, sh, a2, sh2; bool xin; };
 
-__device__ __forceinline__ void point_fetch(const uint8_t* __restrict__ fsrc, const SampleArgs& sa, int gy0,
-                                            int H, int tid, PointRaw& raw) {
+__device__ __forceinline__ PointCol point_columns(const SampleArgs& sa, int tid) {
+    PointCol c;
     const int last = sa.W0 * 3 - 4;            // last byte offset a 4-byte load may start at
     const int gx = tid - 1;
-    const bool xin = gx >= 0;
-    const int xo = xin ? (sa.affine ? sa.xm * gx + sa.xa : sa.sx[gx]) * 3 : 0;
-    const int a = min(xo, last);
-    raw.sh = (xo - a) * 8;
+    c.xin = gx >= 0;
+    const int xo = c.xin ? (sa.affine ? sa.xm * gx + sa.xa : sa.sx[gx]) * 3 : 0;
+    c.a = min(xo, last);
+    c.sh = (xo - c.a) * 8;
+    const int xo2 = (sa.affine ? sa.xm * (kNetW - 1) + sa.xa : sa.sx[kNetW - 1]) * 3;
+    c.a2 = min(xo2, last);
+    c.sh2 = (xo2 - c.a2) * 8;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t point_fetch_piece(const uint8_t* __restrict__ fsrc, const SampleArgs& sa,
+                                                      const PointCol& c, int gy0, int H, int tid, int u) {
+    const int r = u < kC1Rows ? u : tid;
+    const int gy = gy0 + r, gyc = min(max(gy, 0), H - 1);
+    const uint8_t* p = fsrc + (int64_t)(sa.affine ? sa.ym * gyc + sa.ya : sa.sy[gyc]) * sa.row_stride +
+                       (u < kC1Rows ? c.a : c.a2);
+    const bool ok = gy >= 0 && gy < H && (u < kC1Rows ? c.xin : tid < kC1Rows);
+#ifdef CD_ABL_STAGE
+    return (ok && p == nullptr) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
+#else
+    return ok ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
+#endif
+}
+
+__device__ __forceinline__ void put_pixel(float* tile, int r, int c, uint32_t px, bool bgr) {
+    const float f0 = byte_to_unit((float)(px & 255u)), f1 = byte_to_unit((float)((px >> 8) & 255u)),
+                f2 = byte_to_unit((float)((px >> 16) & 255u));
+    tile[(0 * kC1Rows + r) * kC1RS + c] = bgr ? f2 : f0;     // R plane (0 for padding cells)
+    tile[(1 * kC1Rows + r) * kC1RS + c] = f1;
+    tile[(2 * kC1Rows + r) * kC1RS + c] = bgr ? f0 : f2;
+}
+
+__device__ __forceinline__ void point_commit(float* tile, int tid, PointRaw& raw, const PointCol& c, bool bgr) {
+    // (each row's conversion is pinned behind the previous row's LDS writes: scheduled freely, the
+    // conversions of all 36 values are hoisted to where the loads were issued and spill)
 #pragma unroll
     for (int r = 0; r < kC1Rows; ++r) {
-        const int gy = gy0 + r, gyc = min(max(gy, 0), H - 1);
-        const uint8_t* p = fsrc + (int64_t)(sa.affine ? sa.ym * gyc + sa.ya : sa.sy[gyc]) * sa.row_stride + a;
-#ifdef CD_ABL_STAGE
-        raw.v[r] = (xin && gy >= 0 && gy < H && p == nullptr) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
-#else
-        raw.v[r] = (xin && gy >= 0 && gy < H) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
-#endif
+        asm volatile("" : "+v"(raw.v[r]));
+        put_pixel(tile, r, tid, raw.v[r] >> c.sh, bgr);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    {   // column 256 (network column 255), row tid
-        const int xo2 = (sa.affine ? sa.xm * (kNetW - 1) + sa.xa : sa.sx[kNetW - 1]) * 3, a2 = min(xo2, last);
-        raw.sh_x = (xo2 - a2) * 8;
-        const int gy = gy0 + tid, gyc = min(max(gy, 0), H - 1);
-        const uint8_t* p = fsrc + (int64_t)(sa.affine ? sa.ym * gyc + sa.ya : sa.sy[gyc]) * sa.row_stride + a2;
-        raw.v[kC1Rows] = (tid < kC1Rows && gy >= 0 && gy < H) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
-    }
-}
-
-__device__ __forceinline__ void put_pixel(float* tile, const float* slut, int r, int c, uint32_t px, bool bgr) {
-    const uint32_t b0 = px & 255u, b1 = (px >> 8) & 255u, b2 = (px >> 16) & 255u;
-    tile[(0 * kC1Rows + r) * kC1RS + c] = slut[bgr ? b2 : b0];     // R plane (slut[0] == 0: padding)
-    tile[(1 * kC1Rows + r) * kC1RS + c] = slut[b1];
-    tile[(2 * kC1Rows + r) * kC1RS + c] = slut[bgr ? b0 : b2];
-}
-
-__device__ __forceinline__ void point_commit(float* tile, const float* slut, int tid, const PointRaw& raw, bool bgr) {
-#pragma unroll
-    for (int r = 0; r < kC1Rows; ++r) put_pixel(tile, slut, r, tid, raw.v[r] >> raw.sh, bgr);
-    if (tid < kC1Rows) put_pixel(tile, slut, tid, 256, raw.v[kC1Rows] >> raw.sh_x, bgr);
+    asm volatile("" : "+v"(raw.v[kC1Rows]));
+    if (tid < kC1Rows) put_pixel(tile, tid, 256, raw.v[kC1Rows] >> c.sh2, bgr);
 }
 
 // MODE 2: general fixed-point bilinear / 2x2 box.  The two horizontally adjacent source pixels of
@@ -144,7 +168,7 @@ __device__ __forceinline__ void point_commit(float* tile, const float* slut, int
 // loads of a column are in flight before the first is used.  Arithmetic as sample_u8().
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 
-__device__ __forceinline__ void generic_stage(float* tile, const float* slut, const uint8_t* __restrict__ fsrc,
+__device__ __forceinline__ void generic_stage(float* tile, const uint8_t* __restrict__ fsrc,
                                               const SampleArgs& sa, int gy0, int H, int tid, bool bgr) {
     const int last = sa.W0 * 3 - 8;            // last byte offset an 8-byte load may start at
     for (int c = tid; c < 257; c += 256) {
@@ -186,7 +210,7 @@ __device__ __forceinline__ void generic_stage(float* tile, const float* slut, co
                     px |= (uint32_t)v << (8 * cc);
                 }
             }
-            put_pixel(tile, slut, r, c, px, bgr);
+            put_pixel(tile, r, c, px, bgr);
         }
     }
 }
@@ -206,29 +230,30 @@ __device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__
 // MODE 0: fp32 NCHW input.  MODE 1: u8 source, pure point sample (every tap weight is 1).
 // MODE 2: u8 source, general resize.
 //
-// A workgroup walks kC1ChunksPerWG consecutive chunks of one frame.  In MODE 1 the source bytes
-// of chunk k+1 are requested (into registers) before the MFMA work of chunk k starts and are
-// converted and written to LDS after it, so the HBM latency of the gather hides under compute.
+// A workgroup walks `cpw` consecutive chunks of one frame, so the per-lane weights and affine
+// terms are fetched once per workgroup.  In MODE 1 the source bytes of chunk k+1 are requested
+// (into registers) during the MFMA work of chunk k, one load instruction per (wave tile, channel
+// group) unit, and are converted and written to LDS after it.  The L1's miss path sustains only a
+// few such gathers per microsecond (each touches ~8 cache lines that all miss), so a burst of 12
+// per wave blocks the issuing waves for ~10 us; spread out, the gathers drain while the matrix
+// cores work and never fill the queue.
 #ifndef CD_C1_LB
 #define CD_C1_LB 4
 #endif
 template <int MODE>
 __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
-    int chan_order, const float* __restrict__ lut, const float* __restrict__ wfrag,
-    const float* __restrict__ post, const int* __restrict__ tab, float* __restrict__ out, int n, int H, int Hp,
-    int chunks, int groups) {
+    int chan_order, const float* __restrict__ wfrag, float* __restrict__ out, int n, int H, int Hp,
+    int chunks, int groups, int cpw) {
     __shared__ __attribute__((aligned(16))) float tile[kC1Tile];
-    // 4 KB shared by two uses that never overlap: the k/255 table while a chunk is staged, then the
-    // per-wave 16x16 transpose buffers of the epilogue (keeps the workgroup under 40 KB: 4 per CU)
-    __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];
-    float* slut = scratch;
+    __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];   // per-wave 16x16 transposes
+    __shared__ float spost[3 * kC];               // bias / BN scale / BN shift (registers are scarcer)
     const int tid = threadIdx.x;
     int frame, grp;
     xcd_frame_tile(blockIdx.x, groups, frame, grp);
     if (frame >= n) return;
-    const int chunk0 = grp * kC1ChunksPerWG;
-    const int nchunks = min(kC1ChunksPerWG, chunks - chunk0);
+    const int chunk0 = grp * cpw;
+    const int nchunks = min(cpw, chunks - chunk0);
     const bool bgr = chan_order == CD_BGR;
     const uint8_t* fsrc = MODE != 0 ? src + (int64_t)frame * frame_stride : nullptr;
     const float* fx = MODE == 0 ? x + (int64_t)frame * kInC * H * kNetW : nullptr;
@@ -249,16 +274,18 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     // SIMD are issuing MFMAs back to back and, being older, win every arbitration.  Run it at raised
     // priority and drop back before the MFMA loop.
     __builtin_amdgcn_s_setprio(3);
-#ifdef CD_DIAG
-    if (tid == 0) stamps[8] = __builtin_amdgcn_s_memrealtime();
-    {
-        volatile int sink = fsrc != nullptr ? fsrc[0] : 0;   // one dependent global byte load
-        (void)sink;
-    }
-    if (tid == 0) stamps[9] = __builtin_amdgcn_s_memrealtime();
-#endif
     PointRaw raw;
-    if (MODE == 1) point_fetch(fsrc, sa, 9 * chunk0 - 1, H, tid, raw);
+    PointCol pcol{};
+    if (MODE == 1) {
+        pcol = point_columns(sa, tid);
+#pragma unroll
+        for (int u = 0; u < kC1Rows + 1; ++u) {
+#ifdef CD_DIAG
+            if (tid == 0 && (u & 3) == 0) stamps[10 + (u >> 2)] = __builtin_amdgcn_s_memrealtime();
+#endif
+            raw.v[u] = point_fetch_piece(fsrc, sa, pcol, 9 * chunk0 - 1, H, tid, u);
+        }
+    }
 #ifdef CD_DIAG
     if (tid == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -276,57 +303,67 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const int q = lane >> 4, ch = lane & 15;
     float* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
     float* my_out = scratch + wave * 256;
-    // Everything the MFMA loop needs from global memory is fetched once, here, while the tile is
-    // being staged: a load issued inside the loop would cost a full memory round trip (about a
+    // Everything the MFMA loop needs from global memory is fetched once, here, while the first tile
+    // is being staged: a load issued inside the loop would cost a full memory round trip (about a
     // microsecond when the memory pipe is busy with other workgroups' gathers) per 63 MFMAs.
-    float bw[7][3], pbias[3], pscale[3], pshift[3];
+    // The host packs it as 16-byte pieces: 9 loads per lane, each a contiguous KB per wave.
+    float bw[7][3];
+    {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wfrag) + lane;
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-#pragma unroll
-        for (int s = 0; s < 7; ++s) bw[s][nt] = wfrag[(s * 3 + nt) * 64 + lane];
-        pbias[nt] = post[nt * 16 + ch];
-        pscale[nt] = post[kC + nt * 16 + ch];
-        pshift[nt] = post[2 * kC + nt * 16 + ch];
-    }
-    int tabv[4][4];                          // this wave's four tiles: 3 operand bases + store info
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) tabv[k][j] = tab[((wave + 4 * k) * 4 + j) * 16 + i];
-        tabv[k][3] = tab[((wave + 4 * k) * 4 + 3) * 16 + (lane >> 2)];
+        for (int nt = 0; nt < 3; ++nt) {
+            const f32x4 lo = wp[(2 * nt) * 64], hi = wp[(2 * nt + 1) * 64];
+            bw[0][nt] = lo[0]; bw[1][nt] = lo[1]; bw[2][nt] = lo[2]; bw[3][nt] = lo[3];
+            bw[4][nt] = hi[0]; bw[5][nt] = hi[1]; bw[6][nt] = hi[2];
+        }
+        if (tid < 3 * kC) {      // pieces 6..8 hold {bias, scale, shift, 0} per channel (lane & 15)
+            const int c = tid % kC, which = tid / kC;
+            spost[tid] = wfrag[((6 + c / 16) * 64 + (c & 15)) * 4 + which];
+        }
     }
 
     for (int kc = 0; kc < nchunks; ++kc) {
         const int py0 = (chunk0 + kc) * kC1PoolRows;
         const int gy0 = 3 * py0 - 1;        // input row held in LDS row 0
         if (kc > 0) { __syncthreads(); __builtin_amdgcn_s_setprio(3); }   // every wave is done with the previous tile
-        if (MODE != 0) { slut[tid] = lut[tid]; __syncthreads(); }
 #ifdef CD_DIAG
-        if (tid == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+        if (tid == 0 && kc == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && kc == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
 #endif
         if (MODE == 0) f32_stage(tile, fx, gy0, H, tid);
-        else if (MODE == 1) point_commit(tile, slut, tid, raw, bgr);
-        else generic_stage(tile, slut, fsrc, sa, gy0, H, tid, bgr);
+        else if (MODE == 1) point_commit(tile, tid, raw, pcol, bgr);
+        else generic_stage(tile, fsrc, sa, gy0, H, tid, bgr);
 #ifdef CD_DIAG
-        if (tid == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && kc == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
 #endif
         __syncthreads();
         __builtin_amdgcn_s_setprio(0);
 #ifdef CD_DIAG
-        if (tid == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && kc == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (MODE == 1 && kc + 1 < nchunks) point_fetch(fsrc, sa, gy0 + 9, H, tid, raw);
+        const bool more = MODE == 1 && kc + 1 < nchunks;
 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {            // wave tile wt = wave + 4k
+            // (opaque to the compiler: it would otherwise hoist the address arithmetic of all four
+            // tiles out of the chunk loop and keep ~100 registers of addresses alive)
+            int wt = wave + 4 * k;
+            asm volatile("" : "+v"(wt));
+            // LDS offset (floats) of the pixel that A-row i of column group j maps to: window
+            // W = 16wt + 4(i>>2) + (4j + (i&3))/3, column (4j + (i&3)) % 3 of that window
             int base[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) base[j] = tabv[k][j];
+            for (int j = 0; j < 3; ++j) {
+                const int c12 = 4 * j + (i & 3), d = (c12 * 11) >> 5, m = c12 - 3 * d;   // d = c12 / 3
+                const int W = min(16 * wt + 4 * (i >> 2) + d, kC1Windows - 1);
+                const int wr = (W >= kW1 ? 1 : 0) + (W >= 2 * kW1 ? 1 : 0);               // W / 85
+                base[j] = 3 * wr * kC1RS + 3 * (W - wr * kW1) + m;
+            }
             // this lane's piece of the transposed store: window lane>>2, channels 4*(lane&3)..+3
-            const int st = tabv[k][3];
-            const bool st_ok = st >= 0 && py0 + (st & 3) < Hp;
-            float* st_ptr = fout + ((int64_t)py0 * kP1W * kC + (st & ~3) + 4 * (lane & 3));
+            const int Ws = 16 * wt + (lane >> 2);
+            const int wrs = (Ws >= kW1 ? 1 : 0) + (Ws >= 2 * kW1 ? 1 : 0);
+            const bool st_ok = Ws < kC1Windows && py0 + wrs < Hp;
+            float* st_ptr = fout + ((int64_t)(py0 + wrs + 1) * kP1W + (Ws - wrs * kW1) + 1) * kC + 4 * (lane & 3);
             // A-operand addresses of the 7 k-steps x 3 column groups (conv row t is an immediate)
             int addr[7][3];
 #pragma unroll
@@ -334,49 +371,49 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #pragma unroll
                 for (int j = 0; j < 3; ++j) addr[s][j] = base[j] + koff[s];
             // One 16-channel group at a time: 9 accumulators live instead of 27, which keeps the
-            // kernel at 3-4 waves per SIMD so that other waves' MFMAs cover this wave's staging,
+            // kernel at 4 waves per SIMD so that other waves' MFMAs cover this wave's staging,
             // LDS latency and epilogue.  The A values are re-read from LDS for each group.
-#ifdef CD_C1_AREG
-            float a_all[7][3][3];
+            // The three A values of the next conv row (t) are read while the three MFMAs of the
+            // current one run (two sets of three registers; the scheduling barriers keep the compiler
+            // from collapsing this back into read - wait - MFMA on a single register, which leaves a
+            // wave issuing one MFMA per LDS round trip).  The pipeline runs across the channel
+            // groups of a tile: row 0 of the next group has the same addresses as row 0 of this one.
+            float a[2][3];
 #pragma unroll
-            for (int s = 0; s < 7; ++s)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) a_all[s][t][j] = tile[addr[s][j] + t * kC1RS];
-#endif
+            for (int j = 0; j < 3; ++j) a[0][j] = tile[addr[0][j]];
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
-                // accumulators start from the conv bias (every register of a lane is one channel)
-                const float bias = pbias[nt], sc = pscale[nt], sh = pshift[nt];
+                if (kC1MaxChunksPerWG > 1 && more)
+                    raw.v[k * 3 + nt] = point_fetch_piece(fsrc, sa, pcol, gy0 + 9, H, tid, k * 3 + nt);
+                // Accumulators start from the conv bias (every register of a lane is one channel): the
+                // first MFMA of each takes one shared {bias x 4} tuple as its C operand, which costs
+                // nothing, where initialising 36 registers costs 36 VALU slots the MFMAs cannot use.
+                const float bias = spost[nt * 16 + ch];
+                const f32x4 bias4 = f32x4{bias, bias, bias, bias};
                 f32x4 acc[3][3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                for (int row = 0; row < 21; ++row) {
+                    const int s = row / 3, t = row % 3;
+                    const int cur = (nt * 21 + row) & 1;
+                    const int nrow = row < 20 ? row + 1 : 0, ns = nrow / 3, ntt = nrow % 3;
+#ifdef CD_C1_NOPIPE
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[t][j] = f32x4{bias, bias, bias, bias};
+                    for (int j = 0; j < 3; ++j) a[cur][j] = tile[addr[s][j] + t * kC1RS];
 #pragma unroll
-                for (int s = 0; s < 7; ++s) {
-                    const float b = bw[s][nt];
-                    float a[3][3];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t)
-#pragma unroll
-#ifdef CD_C1_AREG
-                        for (int j = 0; j < 3; ++j) a[t][j] = a_all[s][t][j];
-#elif defined(CD_ABL_AREAD)
-                        for (int j = 0; j < 3; ++j) a[t][j] = __int_as_float(addr[s][j] + t);
+                    for (int j = 0; j < 3; ++j) acc[t][j] = mfma4(a[cur][j], bw[s][nt], s == 0 ? bias4 : acc[t][j]);
+                    (void)ns; (void)ntt;
 #else
-                        for (int j = 0; j < 3; ++j) a[t][j] = tile[addr[s][j] + t * kC1RS];
-#endif
+                    if (row < 20 || nt < 2) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
+                        for (int j = 0; j < 3; ++j) a[cur ^ 1][j] = tile[addr[ns][j] + ntt * kC1RS];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-#ifdef CD_ABL_MFMA
-                        for (int j = 0; j < 3; ++j) asm volatile("" :: "v"(a[t][j]), "v"(b));
-#else
-                        for (int j = 0; j < 3; ++j) acc[t][j] = mfma4(a[t][j], b, acc[t][j]);
+                    for (int j = 0; j < 3; ++j) acc[t][j] = mfma4(a[cur][j], bw[s][nt], s == 0 ? bias4 : acc[t][j]);
+                    __builtin_amdgcn_sched_barrier(0);
 #endif
                 }
+                const float sc = spost[kC + nt * 16 + ch], sh = spost[2 * kC + nt * 16 + ch];
                 // epilogue: lane (q, ch) owns pool windows 4q .. 4q+3 of the tile for channel ch + 16 nt.
                 // The 16 windows x 16 channels are transposed through 1 KB of LDS so that every lane
                 // stores 16 contiguous bytes (4 channels of one window).
@@ -407,13 +444,19 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 
 static unsigned xcd_grid(int n, int per_frame) { return (unsigned)(((n + 7) / 8) * 8 * per_frame); }
 
+// Chunks per workgroup: as many as still leave four workgroups for every CU (the most that fit),
+// at most kC1MaxChunksPerWG.
+static int c1_chunks_per_wg(int n, int chunks) {
+    const long total = (long)n * chunks;
+    return (int)std::min<long>(kC1MaxChunksPerWG, std::max<long>(1, total / 1024));
+}
+
 int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s) {
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
     SampleArgs sa{};
-    const int groups = (chunks + kC1ChunksPerWG - 1) / kC1ChunksPerWG;
+    const int cpw = c1_chunks_per_wg(n, chunks), groups = (chunks + cpw - 1) / cpw;
     hipLaunchKernelGGL(conv1_kernel<0>, dim3(xcd_grid(n, groups)), dim3(256), 0, s, x, (const uint8_t*)nullptr, sa,
-                       (int64_t)0, 0, (const float*)nullptr, h->p.w1, h->p.post, h->p.c1tab, h->act1, n, g.h, g.h1, chunks,
-                       groups);
+                       (int64_t)0, 0, h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -424,11 +467,10 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
     SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride,
                   h->rt.affine, h->rt.xm, h->rt.xa, h->rt.ym, h->rt.ya};
     auto kern = h->rt.mode == 1 ? conv1_kernel<1> : conv1_kernel<2>;
-    const int groups = (chunks + kC1ChunksPerWG - 1) / kC1ChunksPerWG;
+    const int cpw = c1_chunks_per_wg(n, chunks), groups = (chunks + cpw - 1) / cpw;
     if (W0 < 3) { set_error("cd_forward_u8: source frames must be at least 3 pixels wide"); return CD_EINVAL; }
     hipLaunchKernelGGL(kern, dim3(xcd_grid(n, groups)), dim3(256), 0, s, (const float*)nullptr, src, sa,
-                       frame_stride, chan_order, h->p.lut, h->p.w1, h->p.post, h->p.c1tab, h->act1, n, g.h, g.h1, chunks,
-                       groups);
+                       frame_stride, chan_order, h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -509,7 +551,6 @@ __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (
 // ------------------------------------------------------------------------------------------
 constexpr int kP2 = 14;
 constexpr int kG2Pix = kP2 * kP2;              // 196 pixels
-constexpr int kG2Floats = kG2Pix * 16;         // one channel group of the patch
 constexpr int kG2Pieces = kG2Pix * 4;          // 16-byte pieces per group patch (784)
 constexpr int kG2Dma = (kG2Pieces + 63) / 64;  // wave-wide DMA instructions per group (13)
 constexpr int kG2BufFloats = kG2Dma * 64 * 4;  // LDS buffer, padded to whole DMA instructions

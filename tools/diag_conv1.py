@@ -30,8 +30,8 @@ print("kernel span us:", end.max(), " WGs:", nwg, " distinct CU ids:", len(np.un
 print("stage phase us: mean %.2f p50 %.2f p90 %.2f max %.2f" % ((mid - start).mean(), np.median(mid - start), np.percentile(mid - start, 90), (mid - start).max()))
 a, b, c = (s[:, 4] - t0) / 100.0, (s[:, 5] - t0) / 100.0, (s[:, 6] - t0) / 100.0
 f = (s[:, 7] - t0) / 100.0
-g8, g9 = (s[:, 8] - t0) / 100.0, (s[:, 9] - t0) / 100.0
-for nm, x in (("start->after index math", g8 - start), ("one dependent byte load", g9 - g8), ("then->gathers issued", f - g9), ("gathers issued->before commit", a - f), ("wait for gathers", b - a), ("commit (LUT + LDS writes, wave 0)", c - b), ("barrier wait", mid - c)):
+u0, u4, u8 = (s[:, 10] - t0) / 100.0, (s[:, 11] - t0) / 100.0, (s[:, 12] - t0) / 100.0
+for nm, x in (("start->first gather", u0 - start), ("gathers 0-3", u4 - u0), ("gathers 4-7", u8 - u4), ("gathers 8-11", f - u8), ("gathers issued->before commit", a - f), ("wait for gathers", b - a), ("commit (LUT + LDS writes, wave 0)", c - b), ("barrier wait", mid - c)):
     print("  %-40s mean %.2f p50 %.2f p90 %.2f" % (nm, x.mean(), np.median(x), np.percentile(x, 90)))
 print("compute phase us: mean %.2f p50 %.2f p90 %.2f max %.2f" % ((end - mid).mean(), np.median(end - mid), np.percentile(end - mid, 90), (end - mid).max()))
 print("WG life us: mean %.2f" % (end - start).mean())
@@ -46,3 +46,17 @@ print("WGs per CU: min %d max %d" % (min(cnts), max(cnts)))
 lastend = np.array([max(b for a, b in v) for v in per.values()])
 print("per-CU last end us: min %.1f p50 %.1f max %.1f" % (lastend.min(), np.median(lastend), lastend.max()))
 print("start time of WGs: p50 %.1f p90 %.1f max %.1f" % (np.median(start), np.percentile(start, 90), start.max()))
+# phase clustering: how many workgroups of a CU are in their staging phase at the same time
+hist = np.histogram(start, bins=np.arange(0, end.max() + 5, 5))[0]
+print("WG starts per 5 us bin:", " ".join(str(v) for v in hist))
+grid = np.arange(0, end.max(), 0.5)
+staging = np.zeros((len(per), len(grid)), dtype=np.int32)
+resident = np.zeros((len(per), len(grid)), dtype=np.int32)
+ids = {c: k for k, c in enumerate(per)}
+for c, a, m, b in zip(cuid, start, mid, end):
+    k = ids[c]
+    staging[k] += (grid >= a) & (grid < m)
+    resident[k] += (grid >= a) & (grid < b)
+computing = resident - staging
+print("time share of a CU with k workgroups in the MFMA phase: " + " ".join("k=%d %.3f" % (k, (computing == k).mean()) for k in range(6)))
+print("time share of a CU with k workgroups staging:           " + " ".join("k=%d %.3f" % (k, (staging == k).mean()) for k in range(6)))

@@ -1,7 +1,7 @@
 # Times the bench with each library variant under cut-detection_amd/lib/variants (ablation builds).
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for lib in cut-detection_amd/lib/libcutdet.so cut-detection_amd/lib/variants/*.so; do
+for lib in cut-detection_amd/lib/libcutdet.so cut-detection_amd/lib/libcutdet.so $(ls cut-detection_amd/lib/variants/*.so 2>/dev/null); do
   echo "== $lib"
   CUTDET_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 40 --warmup 4 --no-cpu-baseline 2>gpurun_out/var.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], {k:v['ms_total'] for k,v in d['stages'].items()})" || { tail -5 gpurun_out/var.err; exit 1; }
 done
