@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--height", type=int, default=H0, help="source frame height (default: the 720p headline)")
     ap.add_argument("--width", type=int, default=W0, help="source frame width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-timing", choices=["dominant", "all", "off"], default="dominant",
+                    help="which kernels are bracketed with HIP events inside the timed region: the dominant "
+                         "one (block 2, what the roofline object reports), every stage (each event pair costs "
+                         "a few microseconds of stream time per launch), or none")
     ap.add_argument("--cpu-sample-batches", type=int, default=10)
     return ap.parse_args()
 
@@ -160,7 +164,10 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region
-    eng.timing_enable(True)
+    if args.stage_timing == "dominant":
+        eng.timing_enable(True, stages=["conv2"])
+    else:
+        eng.timing_enable(args.stage_timing == "all")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -94,7 +94,7 @@ struct cd_handle {
     int64_t* rle_blocks;    // workspace of cd_rle: per-block boundary counts / offsets
     int rle_blocks_cap;
     // optional per-stage timing: HIP event pairs recorded around each stage's launches
-    bool timing;
+    unsigned timing;   // bit i set: launches of stage i are bracketed
     std::vector<hipEvent_t> ev_start[CD_STAGE_COUNT], ev_stop[CD_STAGE_COUNT];
     size_t ev_used[CD_STAGE_COUNT];
 };

@@ -226,7 +226,7 @@ struct StageTimer {
     hipStream_t s;
     bool live = false;
     StageTimer(cd_handle* h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_) {
-        if (!h->timing) return;
+        if (!((h->timing >> stage) & 1u)) return;
         size_t k = h->ev_used[stage];
         if (k == h->ev_start[stage].size()) {
             hipEvent_t a, b;
@@ -450,7 +450,8 @@ int cd_debug_peek_act2(cd_handle* h, size_t byte_off, size_t nbytes, void* host_
 
 int cd_timing_enable(cd_handle* h, int on) {
     if (!h) { set_error("cd_timing_enable: null handle"); return CD_EINVAL; }
-    h->timing = on != 0;
+    // 0 off, 1 every stage, otherwise bit (stage + 1) selects a stage
+    h->timing = on == 1 ? ~0u : (unsigned)on >> 1;
     if (!on) for (int st = 0; st < CD_STAGE_COUNT; ++st) h->ev_used[st] = 0;
     return CD_OK;
 }

@@ -153,8 +153,16 @@ class Engine:
         return {"end_frames": end[:s], "frame_types": typ[:s], "run_lengths": rl[:s], "start_frames": st[:s],
                 "score_means": mean[:s], "score_sums": ssum[:s]}
 
-    def timing_enable(self, on=True):
-        check(lib.cd_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, on=True, stages=None):
+        """Bracket stage launches with HIP events: all stages, or only the named ones (an event pair
+        costs a few microseconds of stream time per launch)."""
+        if on and stages:
+            mask = 0
+            for name in stages:
+                mask |= 1 << (_lib.STAGES.index(name) + 1)
+            check(lib.cd_timing_enable(self._h, mask))
+        else:
+            check(lib.cd_timing_enable(self._h, 1 if on else 0))
 
     def timing_read(self):
         """{stage: (launches, total_ms)} for the launches bracketed since the last read (syncs)."""

@@ -106,9 +106,12 @@ int cd_rle(cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64
 int cd_synth_frames(cd_handle* h, uint8_t* dst, int n, int H0, int W0,
                     const uint8_t* classes, uint32_t seed, int64_t first_index, void* stream);
 
-/* Per-stage device timing.  While enabled, every stage launch is bracketed by a pair of HIP
- * events on the caller's stream.  cd_timing_read() waits for the recorded events of `stage`,
- * returns how many launches were bracketed and their summed duration, and forgets them.
+/* Per-stage device timing.  While enabled, the launches of the selected stages are bracketed by
+ * pairs of HIP events on the caller's stream.  `on`: 0 = off, 1 = every stage, otherwise a mask
+ * with bit (CD_STAGE_x + 1) set for each stage to time (an event pair costs a few microseconds
+ * of stream time, so a benchmark times only the kernel it reports on).  cd_timing_read() waits
+ * for the recorded events of `stage`, returns how many launches were bracketed and their summed
+ * duration, and forgets them.
  * No counterpart in the reference; used by bench.py for the per-kernel roofline figures. */
 int cd_timing_enable(cd_handle* h, int on);
 int cd_timing_read(cd_handle* h, int stage, int64_t* launches, double* total_ms);
