@@ -52,8 +52,8 @@ struct Geometry {               // per network-input height
 };
 inline Geometry geometry(int h) { Geometry g; g.h = h; g.h1 = h / 3; g.h2 = g.h1 / 3; g.h3 = g.h2 / 3; return g; }
 // LDS of the block-3 + head kernel: padded block-2 frame, pooled block-3 tensor, features, hidden units
-inline size_t head_lds_bytes(const Geometry& g) {
-    return sizeof(float) * ((size_t)(g.h2 + 2) * (kW2 + 2) * kC + (size_t)g.h3 * kW3 * kC + kFeat + kHid);
+inline size_t head_lds_bytes(const Geometry& g, int elem_bytes) {
+    return (size_t)elem_bytes * (g.h2 + 2) * (kW2 + 2) * kC + sizeof(float) * ((size_t)g.h3 * kW3 * kC + kFeat + kHid);
 }
 
 // ---- resize tables (device) -------------------------------------------------------------------
@@ -67,9 +67,11 @@ struct ResizeTables {
 
 // ---- packed parameters on the device ----------------------------------------------------------
 struct DeviceParams {
-    float* w1;    // conv1 B fragments  [7 k-steps][3 n-tiles][64 lanes]
+    float* w1;    // conv1: [9 pieces][64 lanes][4]: B fragments (pieces 0-5), bias / BN scale / BN shift (6-8)
     float* w2;    // conv2 B fragments  [27 steps][3 n-tiles][64 lanes][4]
     float* w3;    // conv3 B fragments  (same layout as w2)
+    uint16_t* w2b;  // conv2 / conv3 B fragments in bf16: [27 steps][3 n-tiles][64 lanes][4]
+    uint16_t* w3b;
     float* post;  // [3 layers][3][48]: conv bias, BN scale, BN shift
     float* fc0w;  // [32][768]
     float* fc0p;  // [3][32]: bias, BN scale, BN shift

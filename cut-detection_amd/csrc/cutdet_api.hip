@@ -39,7 +39,16 @@ void bn_affine(const float* g, const float* beta, const float* mu, const float* 
     }
 }
 
-struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut; };
+struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b; };
+
+// float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 and torch's .bfloat16() do)
+static uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
 
 // Packs everything the kernels read into one host image; `off` receives where each section
 // starts (in floats) so the caller can rebase them onto the device allocation.
@@ -101,6 +110,13 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
                                 cv[l].w[((size_t)oc * kC + ci) * 9 + kk];
                         }
     }
+    // the same fragments in bf16 (round to nearest even), two per float slot of the image
+    const size_t o_w2b = section(27 * 3 * 64 * 2), o_w3b = section(27 * 3 * 64 * 2);
+    for (int l = 1; l < 3; ++l) {
+        const size_t src = l == 1 ? o_w2 : o_w3, dst = l == 1 ? o_w2b : o_w3b;
+        uint16_t* d = reinterpret_cast<uint16_t*>(&img[dst]);
+        for (size_t k = 0; k < (size_t)27 * 3 * 64 * 4; ++k) d[k] = bf16_rne(img[src + k]);
+    }
     for (int l = 0; l < 3; ++l) {
         float* p = &img[o_post + (size_t)l * 3 * kC];
         std::memcpy(p, cv[l].b, kC * sizeof(float));
@@ -119,7 +135,7 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     std::memcpy(&img[o_fc1b], fc1b, kOut * sizeof(float));
     for (int k = 0; k < 256; ++k) img[o_lut + k] = (float)k / 255.0f;   // data.py:227 divides, it does not scale
 
-    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut};
+    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b};
     return img;
 }
 
@@ -208,11 +224,11 @@ int ensure_workspace(cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     return CD_OK;
 }
 
-int check_net_shape(int n, int net_h, int net_w, Geometry* g) {
+int check_net_shape(const cd_handle* h, int n, int net_h, int net_w, Geometry* g) {
     if (n < 1) { set_error("batch of %d frames", n); return CD_EINVAL; }
     if (net_w != kNetW) { set_error("network input width must be %d, got %d", kNetW, net_w); return CD_EINVAL; }
     *g = geometry(net_h);
-    if (g->h3 < 1 || net_h > kMaxNetH || head_lds_bytes(*g) > (size_t)kLdsBytes) {
+    if (g->h3 < 1 || net_h > kMaxNetH || head_lds_bytes(*g, h->dtype == CD_BF16 ? 2 : 4) > (size_t)kLdsBytes) {
         set_error("network input height %d unsupported (27..%d rows)", net_h, kMaxNetH);
         return CD_EINVAL;
     }
@@ -268,7 +284,7 @@ const char* cd_last_error(void) { return cd::g_err; }
 int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int device, int dtype) {
     if (!out || !weights_blob) { set_error("cd_create: null argument"); return CD_EINVAL; }
     *out = nullptr;
-    if (dtype != CD_F32) { set_error("cd_create: dtype %d not supported (0 = f32)", dtype); return CD_EINVAL; }
+    if (dtype != CD_F32 && dtype != CD_BF16) { set_error("cd_create: dtype %d not supported (0 = f32, 1 = bf16)", dtype); return CD_EINVAL; }
     const unsigned char* b = static_cast<const unsigned char*>(weights_blob);
     if (nbytes < kHeader || std::memcmp(b, kMagic, 8) != 0) { set_error("cd_create: not a weight blob"); return CD_EINVAL; }
     uint32_t hd[8];
@@ -303,6 +319,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->p.w1 = base + off.w1; h->p.w2 = base + off.w2; h->p.w3 = base + off.w3; h->p.post = base + off.post;
     h->p.fc0w = base + off.fc0w; h->p.fc0p = base + off.fc0p; h->p.fc1w = base + off.fc1w;
     h->p.fc1b = base + off.fc1b; h->p.lut = base + off.lut;
+    h->p.w2b = reinterpret_cast<uint16_t*>(base + off.w2b); h->p.w3b = reinterpret_cast<uint16_t*>(base + off.w3b);
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);
     const size_t t_short = align_up((size_t)2 * kMaxSrcW * sizeof(short), 256);
@@ -338,7 +355,7 @@ void cd_destroy(cd_handle* h) {
 int cd_reserve(cd_handle* h, int max_frames, int net_h) {
     if (!h) { set_error("cd_reserve: null handle"); return CD_EINVAL; }
     Geometry g;
-    int rc = check_net_shape(max_frames, net_h, kNetW, &g);
+    int rc = check_net_shape(h, max_frames, net_h, kNetW, &g);
     if (rc) return rc;
     DeviceGuard guard(h->device);
     return ensure_workspace(h, max_frames, g, nullptr);
@@ -372,7 +389,7 @@ int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w, float*
                int64_t* argmax, void* stream) {
     if (!h || !x || !logits) { set_error("cd_forward: null argument"); return CD_EINVAL; }
     Geometry g;
-    int rc = check_net_shape(n, net_h, net_w, &g);
+    int rc = check_net_shape(h, n, net_h, net_w, &g);
     if (rc) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -390,7 +407,7 @@ int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64
     int rc = check_src("cd_forward_u8", src, n, H0, W0, row_stride, frame_stride, chan_order);
     if (rc) return rc;
     Geometry g;
-    if ((rc = check_net_shape(n, net_h, net_w, &g))) return rc;
+    if ((rc = check_net_shape(h, n, net_h, net_w, &g))) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;

@@ -30,20 +30,57 @@ namespace cd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kW48Bytes = 27 * 3 * 64 * 16;    // packed B fragments of one 48 -> 48 layer
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// Storage type of the activations between blocks and of the block-2/3 weights.  A fragment is a
+// lane's share of an MFMA operand for one 16-wide K step: four fp32 values feed four
+// v_mfma_f32_16x16x4_f32 (K slots 4e + kq), four bf16 values feed one v_mfma_f32_16x16x16_bf16
+// (K slots 4kq + e) - the same four input channels either way, so both precisions share every
+// index computation.  Accumulation is fp32 in both.
+template <bool BF> struct Prec;
+template <> struct Prec<false> {
+    typedef float elem; typedef f32x4 frag;
+    static constexpr int kSub = 4;          // MFMAs per fragment pair
+    static constexpr int kEs = 4;           // bytes per element
+};
+template <> struct Prec<true> {
+    typedef uint16_t elem; typedef bf16x4 frag;
+    static constexpr int kSub = 1;
+    static constexpr int kEs = 2;
+};
 
 // Weight fragments are read through a buffer descriptor: the address is one per-lane VGPR
-// (lane * 16) plus a scalar offset, so the 81 loads of a tile cost no vector address arithmetic
-// and nothing for the compiler to hoist into registers.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float* w) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, kW48Bytes, 0x00020000);
+// (lane * fragment bytes) plus a scalar offset, so the 81 loads of a tile cost no vector address
+// arithmetic and nothing for the compiler to hoist into registers.
+template <bool BF>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* w) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 27 * 3 * 64 * 4 * Prec<BF>::kEs, 0x00020000);
 }
-__device__ __forceinline__ f32x4 load_frag(__amdgpu_buffer_rsrc_t r, int lane16, int byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, byte_off, 0));
+// fragment `idx` (= step * 3 + n-tile) of a layer's packed weights
+template <bool BF>
+__device__ __forceinline__ typename Prec<BF>::frag load_frag(__amdgpu_buffer_rsrc_t r, int lane, int idx) {
+    if constexpr (BF)
+        return __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8, idx * 512, 0));
+    else
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// sub-step e of a fragment pair (fp32: e = 0..3; bf16: e = 0 only)
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma_frag(const typename Prec<BF>::frag& a, const typename Prec<BF>::frag& b, int e,
+                                           f32x4 c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    else return mfma4(a[e], b[e], c);
+}
+// two fp32 values -> two bf16 (round to nearest even) in one dword, `lo` in the low half
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
 // Pool-window max of one lane: columns 3*wi .. 3*wi+2 of its 12 columns, rows t = 0..2.
@@ -240,11 +277,12 @@ __device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__
 #ifndef CD_C1_LB
 #define CD_C1_LB 4
 #endif
-template <int MODE>
+template <int MODE, bool OBF>
 __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
-    int chan_order, const float* __restrict__ wfrag, float* __restrict__ out, int n, int H, int Hp,
+    int chan_order, const float* __restrict__ wfrag, typename Prec<OBF>::elem* __restrict__ out, int n, int H, int Hp,
     int chunks, int groups, int cpw) {
+    typedef typename Prec<OBF>::elem elem;       // the arithmetic is fp32 either way; OBF stores bf16
     __shared__ __attribute__((aligned(16))) float tile[kC1Tile];
     __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];   // per-wave 16x16 transposes
     __shared__ float spost[3 * kC];               // bias / BN scale / BN shift (registers are scarcer)
@@ -261,7 +299,7 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #ifdef CD_DIAG
     // diagnostic build: per-workgroup time stamps go to the slack frame behind the batch
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(out + (int64_t)n * (Hp + 2) * kP1W * kC) + 16 * blockIdx.x;
-    if (tid == 0) {
+    if (!OBF && tid == 0) {
         stamps[0] = __builtin_amdgcn_s_memrealtime();
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -281,13 +319,13 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #pragma unroll
         for (int u = 0; u < kC1Rows + 1; ++u) {
 #ifdef CD_DIAG
-            if (tid == 0 && (u & 3) == 0) stamps[10 + (u >> 2)] = __builtin_amdgcn_s_memrealtime();
+            if (!OBF && tid == 0 && (u & 3) == 0) stamps[10 + (u >> 2)] = __builtin_amdgcn_s_memrealtime();
 #endif
             raw.v[u] = point_fetch_piece(fsrc, sa, pcol, 9 * chunk0 - 1, H, tid, u);
         }
     }
 #ifdef CD_DIAG
-    if (tid == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
+    if (!OBF && tid == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
 #endif
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -301,7 +339,7 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
         koff[s] = (ci * kC1Rows + ky) * kC1RS + kx;
     }
     const int q = lane >> 4, ch = lane & 15;
-    float* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
+    elem* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
     float* my_out = scratch + wave * 256;
     // Everything the MFMA loop needs from global memory is fetched once, here, while the first tile
     // is being staged: a load issued inside the loop would cost a full memory round trip (about a
@@ -327,19 +365,19 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
         const int gy0 = 3 * py0 - 1;        // input row held in LDS row 0
         if (kc > 0) { __syncthreads(); __builtin_amdgcn_s_setprio(3); }   // every wave is done with the previous tile
 #ifdef CD_DIAG
-        if (tid == 0 && kc == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0 && kc == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+        if (!OBF && tid == 0 && kc == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
+        if (!OBF && tid == 0 && kc == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
 #endif
         if (MODE == 0) f32_stage(tile, fx, gy0, H, tid);
         else if (MODE == 1) point_commit(tile, tid, raw, pcol, bgr);
         else generic_stage(tile, fsrc, sa, gy0, H, tid, bgr);
 #ifdef CD_DIAG
-        if (tid == 0 && kc == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
+        if (!OBF && tid == 0 && kc == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
 #endif
         __syncthreads();
         __builtin_amdgcn_s_setprio(0);
 #ifdef CD_DIAG
-        if (tid == 0 && kc == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+        if (!OBF && tid == 0 && kc == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
 #endif
         const bool more = MODE == 1 && kc + 1 < nchunks;
 
@@ -363,7 +401,7 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
             const int Ws = 16 * wt + (lane >> 2);
             const int wrs = (Ws >= kW1 ? 1 : 0) + (Ws >= 2 * kW1 ? 1 : 0);
             const bool st_ok = Ws < kC1Windows && py0 + wrs < Hp;
-            float* st_ptr = fout + ((int64_t)(py0 + wrs + 1) * kP1W + (Ws - wrs * kW1) + 1) * kC + 4 * (lane & 3);
+            elem* st_ptr = fout + ((int64_t)(py0 + wrs + 1) * kP1W + (Ws - wrs * kW1) + 1) * kC + 4 * (lane & 3);
             // A-operand addresses of the 7 k-steps x 3 column groups (conv row t is an immediate)
             int addr[7][3];
 #pragma unroll
@@ -424,12 +462,12 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
                 __builtin_amdgcn_wave_barrier();
                 {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + (lane >> 2) * 16 + 4 * (lane & 3));
-#ifdef CD_ABL_EPI
-                    if (st_ok && v[0] == 123456.f)
-#else
-                    if (st_ok)
-#endif
-                        *reinterpret_cast<f32x4*>(st_ptr + nt * 16) = v;
+                    if (st_ok) {
+                        if constexpr (OBF)
+                            *reinterpret_cast<uint2*>(st_ptr + nt * 16) = uint2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                        else
+                            *reinterpret_cast<f32x4*>(st_ptr + nt * 16) = v;
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read done before the next group rewrites
                 __builtin_amdgcn_wave_barrier();
@@ -438,7 +476,7 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     }
 #ifdef CD_DIAG
     __syncthreads();
-    if (tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+    if (!OBF && tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -451,12 +489,23 @@ static int c1_chunks_per_wg(int n, int chunks) {
     return (int)std::min<long>(kC1MaxChunksPerWG, std::max<long>(1, total / 1024));
 }
 
+template <int MODE>
+static void launch_conv1(const cd_handle* h, unsigned grid, hipStream_t s, const float* x, const uint8_t* src,
+                         const SampleArgs& sa, int64_t frame_stride, int chan_order, int n, const Geometry& g,
+                         int chunks, int groups, int cpw) {
+    if (h->dtype == CD_BF16)
+        hipLaunchKernelGGL((conv1_kernel<MODE, true>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
+                           (const float*)h->p.w1, reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw);
+    else
+        hipLaunchKernelGGL((conv1_kernel<MODE, false>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
+                           (const float*)h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw);
+}
+
 int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s) {
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
     SampleArgs sa{};
     const int cpw = c1_chunks_per_wg(n, chunks), groups = (chunks + cpw - 1) / cpw;
-    hipLaunchKernelGGL(conv1_kernel<0>, dim3(xcd_grid(n, groups)), dim3(256), 0, s, x, (const uint8_t*)nullptr, sa,
-                       (int64_t)0, 0, h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw);
+    launch_conv1<0>(h, xcd_grid(n, groups), s, x, nullptr, sa, 0, 0, n, g, chunks, groups, cpw);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -466,47 +515,48 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
     SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride,
                   h->rt.affine, h->rt.xm, h->rt.xa, h->rt.ym, h->rt.ya};
-    auto kern = h->rt.mode == 1 ? conv1_kernel<1> : conv1_kernel<2>;
     const int cpw = c1_chunks_per_wg(n, chunks), groups = (chunks + cpw - 1) / cpw;
     if (W0 < 3) { set_error("cd_forward_u8: source frames must be at least 3 pixels wide"); return CD_EINVAL; }
-    hipLaunchKernelGGL(kern, dim3(xcd_grid(n, groups)), dim3(256), 0, s, (const float*)nullptr, src, sa,
-                       frame_stride, chan_order, h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw);
+    if (h->rt.mode == 1) launch_conv1<1>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
+    else launch_conv1<2>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
 
 // ------------------------------------------------------------------------------------------
-// 48 -> 48 channel wave tile (blocks 2 and 3), K = 432 = 27 steps of (ky, kx, 16-channel group)
-// x 4 k-steps.  `patch` is channel-last fp32 in LDS with pixel stride kC floats; a lane's A
-// values for the 4 k-steps of a step are one ds_read_b128 at
-//     patch[base[j] + ((t + ky) * pitch + kx) * kC + 16 g],   base[j] includes 4 * (lane >> 4).
-// k-step e of step (ky, kx, g) therefore covers input channels 16 g + 4 kq + e (kq = 0..3);
-// the packed weights use the same order.
+// 48 -> 48 channel wave tile (blocks 2 and 3), K = 432 = 27 steps of (ky, kx, 16-channel group).
+// `patch` is channel-last in LDS with pixel stride kC elements; a lane's A fragment of a step is
+// one 16-byte (fp32) or 8-byte (bf16) LDS read at
+//     patch[base[j] + ((t + ky) * pitch + kx) * kC + 16 g],   base[j] includes 4 * (lane >> 4),
+// i.e. input channels 16 g + 4 kq .. + 3 (kq = lane >> 4); the packed weights use the same order.
 // ------------------------------------------------------------------------------------------
 // The 27 steps are fully unrolled and software-pipelined by hand: the operands of step s+1 (nine
-// 16-byte LDS reads, three 16-byte weight loads that hit L1/L2) are requested before the 108 MFMAs
-// of step s and first used after them.  The scheduling barriers keep the compiler from sinking
-// the loads down to their first use, which would expose the L2 latency once per step.
-template <int PITCH>
-__device__ __forceinline__ void conv48_load_step(const float* patch, const int (&base)[3],
-                                                 __amdgpu_buffer_rsrc_t wr, int lane16, int s, f32x4 (&a)[3][3],
-                                                 f32x4 (&b)[3]) {
+// LDS reads, three weight loads that hit L1/L2) are requested during the MFMAs of step s and first
+// used after them.  The scheduling barriers keep the compiler from sinking the loads down to
+// their first use, which would expose the L2 latency once per step.
+template <int PITCH, bool BF>
+__device__ __forceinline__ void conv48_load_step(const typename Prec<BF>::elem* patch, const int (&base)[3],
+                                                 __amdgpu_buffer_rsrc_t wr, int lane, int s,
+                                                 typename Prec<BF>::frag (&a)[3][3], typename Prec<BF>::frag (&b)[3]) {
+    typedef typename Prec<BF>::frag frag;
     const int kk = s / 3, g = s % 3;
     const int off = ((kk / 3) * PITCH + (kk % 3)) * kC + 16 * g;
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) b[nt] = load_frag(wr, lane16, (s * 3 + nt) * 1024);
+    for (int nt = 0; nt < 3; ++nt) b[nt] = load_frag<BF>(wr, lane, s * 3 + nt);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            a[t][j] = *reinterpret_cast<const f32x4*>(patch + base[j] + off + t * PITCH * kC);
+            a[t][j] = *reinterpret_cast<const frag*>(patch + base[j] + off + t * PITCH * kC);
 }
 
-template <int PITCH>
-__device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (&base)[3],
-                                                 __amdgpu_buffer_rsrc_t wr, int lane16, f32x4 (&acc)[3][3][3]) {
-    f32x4 a[2][3][3], b[2][3];
-    conv48_load_step<PITCH>(patch, base, wr, lane16, 0, a[0], b[0]);
+template <int PITCH, bool BF>
+__device__ __forceinline__ void conv48_wave_tile(const typename Prec<BF>::elem* patch, const int (&base)[3],
+                                                 __amdgpu_buffer_rsrc_t wr, int lane, f32x4 (&acc)[3][3][3]) {
+    typedef typename Prec<BF>::frag frag;
+    constexpr int kM = 27 * Prec<BF>::kSub;      // MFMAs per step
+    frag a[2][3][3], b[2][3];
+    conv48_load_step<PITCH, BF>(patch, base, wr, lane, 0, a[0], b[0]);
 #pragma unroll
     for (int s = 0; s < 27; ++s) {
         const int cur = s & 1;
@@ -516,19 +566,19 @@ __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (
         // anything issued as a block between two MFMAs leaves the matrix pipe idle
         const int n_side = s + 1 < 27 ? 12 : 0;
 #pragma unroll
-        for (int m = 0; m < 108; ++m) {
+        for (int m = 0; m < kM; ++m) {
             const int e = m / 27, t = (m / 9) % 3, j = (m / 3) % 3, nt = m % 3;
             if (s == 0 && e == 0)
-                acc[t][j][nt] = mfma4(a[cur][t][j][e], b[cur][nt][e], f32x4{0.f, 0.f, 0.f, 0.f});
+                acc[t][j][nt] = mfma_frag<BF>(a[cur][t][j], b[cur][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
             else
-                acc[t][j][nt] = mfma4(a[cur][t][j][e], b[cur][nt][e], acc[t][j][nt]);
+                acc[t][j][nt] = mfma_frag<BF>(a[cur][t][j], b[cur][nt], e, acc[t][j][nt]);
             if (m < n_side) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (m < 3) {
-                    b[cur ^ 1][m] = load_frag(wr, lane16, ((s + 1) * 3 + m) * 1024);
+                    b[cur ^ 1][m] = load_frag<BF>(wr, lane, (s + 1) * 3 + m);
                 } else {
                     const int lt = (m - 3) / 3, lj = (m - 3) % 3;
-                    a[cur ^ 1][lt][lj] = *reinterpret_cast<const f32x4*>(patch + base[lj] + off + lt * PITCH * kC);
+                    a[cur ^ 1][lt][lj] = *reinterpret_cast<const frag*>(patch + base[lj] + off + lt * PITCH * kC);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -551,52 +601,65 @@ __device__ __forceinline__ void conv48_wave_tile(const float* patch, const int (
 // ------------------------------------------------------------------------------------------
 constexpr int kP2 = 14;
 constexpr int kG2Pix = kP2 * kP2;              // 196 pixels
-constexpr int kG2Pieces = kG2Pix * 4;          // 16-byte pieces per group patch (784)
-constexpr int kG2Dma = (kG2Pieces + 63) / 64;  // wave-wide DMA instructions per group (13)
-constexpr int kG2BufFloats = kG2Dma * 64 * 4;  // LDS buffer, padded to whole DMA instructions
+// per precision: 16-byte pieces of one channel group of a patch (16 channels x element size per
+// pixel), wave-wide DMA instructions that copy them, and the LDS buffer padded to whole instructions
+template <bool BF> struct G2 {
+    static constexpr int kEs = Prec<BF>::kEs;
+    static constexpr int kPieces = kG2Pix * kEs;            // 784 fp32, 392 bf16
+    static constexpr int kDma = (kPieces + 63) / 64;        // 13 fp32, 7 bf16
+    static constexpr int kBufElems = kDma * 1024 / kEs;
+};
 
-struct Conv2Tile { const char* src; float* dst; int ty, tx; };
+template <bool BF> struct Conv2Tile { const char* src; typename Prec<BF>::elem* dst; int ty, tx; };
 
-__device__ __forceinline__ void conv2_load_step(const float* buf, const int (&base)[3],
-                                                __amdgpu_buffer_rsrc_t wr, int lane16, int g, int kk,
-                                                f32x4 (&a)[3][3], f32x4 (&b)[3]) {
+template <bool BF>
+__device__ __forceinline__ void conv2_load_step(const typename Prec<BF>::elem* buf, const int (&base)[3],
+                                                __amdgpu_buffer_rsrc_t wr, int lane, int g, int kk,
+                                                typename Prec<BF>::frag (&a)[3][3], typename Prec<BF>::frag (&b)[3]) {
+    typedef typename Prec<BF>::frag frag;
     const int off = ((kk / 3) * kP2 + (kk % 3)) * 16;
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) b[nt] = load_frag(wr, lane16, g * 3072 + (kk * 9 + nt) * 1024);
+    for (int nt = 0; nt < 3; ++nt) b[nt] = load_frag<BF>(wr, lane, (kk * 3 + g) * 3 + nt);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            a[t][j] = *reinterpret_cast<const f32x4*>(buf + base[j] + off + t * kP2 * 16);
+            a[t][j] = *reinterpret_cast<const frag*>(buf + base[j] + off + t * kP2 * 16);
 }
 
-// LDS-DMA of one channel group of a patch: 13 wave-wide 16-byte copies, LDS image linear.
+// LDS-DMA of one channel group of a patch: wave-wide 16-byte copies, LDS image linear.
 // All 64 lanes take part in the last copy as well (no exec-masked region: a branch here makes the
-// compiler shuttle all 108 accumulators between AGPRs and VGPRs once per unit): its 48 surplus
-// pieces read the first 12 pixels of patch row 14, which exist (next rows of the padded frame or
-// the slack frame), and land in the padding at the end of the LDS buffer.
-__device__ __forceinline__ void conv2_dma_group(const char* src, float* dst, const int (&rel)[kG2Dma], int lane) {
+// compiler shuttle all 108 accumulators between AGPRs and VGPRs once per unit): its surplus
+// pieces read the first pixels of patch rows 14 and 15, which exist (next rows of the padded frame
+// or the slack frame), and land in the padding at the end of the LDS buffer.
+template <bool BF>
+__device__ __forceinline__ void conv2_dma_group(const char* src, typename Prec<BF>::elem* dst,
+                                                const int (&rel)[G2<BF>::kDma], int lane) {
     char* d = reinterpret_cast<char*>(dst);
 #pragma unroll
-    for (int it = 0; it < kG2Dma; ++it)
+    for (int it = 0; it < G2<BF>::kDma; ++it)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)rel[it]),
                                          (__attribute__((address_space(3))) void*)(d + it * 1024), 16, 0, 0);
 }
 
-// One (tile, channel group) unit: 9 pipelined steps of 108 MFMAs.  G, the channel group, is a
-// compile-time constant and a tile always starts with operand set 0, so the set each of the 27 steps
-// of a tile reads is fixed at compile time.  Which LDS buffer holds the unit's patch alternates
-// from unit to unit and from tile to tile (a tile is an odd number of units); `mine_off` and
-// `other_off` (floats) select them at run time.  The first MFMA of each accumulator in a tile takes
-// a literal zero as its C operand, so the accumulators are defined and consumed inside one tile
-// body and never cross the loop edge (the compiler otherwise permutes all 108 of them through
-// VGPRs once per unit).
-template <int G>
-__device__ __forceinline__ void conv2_unit(const float* bufs, int mine_off, int other_off, const char* next_src,
-                                           const int (&rel)[kG2Dma], const int (&base)[3],
-                                           __amdgpu_buffer_rsrc_t wr, int lane,
-                                           f32x4 (&a)[2][3][3], f32x4 (&b)[2][3], f32x4 (&acc)[3][3][3]) {
-    // everything outstanding was issued at least one step (108 MFMAs) ago
+// One (tile, channel group) unit: 9 pipelined steps.  G, the channel group, is a compile-time
+// constant and a tile always starts with operand set 0, so the set each of the 27 steps of a tile
+// reads is fixed at compile time.  Which LDS buffer holds the unit's patch alternates from unit to
+// unit and from tile to tile (a tile is an odd number of units); `mine_off` and `other_off`
+// (elements) select them at run time.  The first MFMA of each accumulator in a tile takes a literal
+// zero as its C operand, so the accumulators are defined and consumed inside one tile body and
+// never cross the loop edge (the compiler otherwise permutes all 108 of them through VGPRs once
+// per unit).
+template <int G, bool BF>
+__device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, int mine_off, int other_off,
+                                           const char* next_src, const int (&rel)[G2<BF>::kDma],
+                                           const int (&base)[3], __amdgpu_buffer_rsrc_t wr, int lane,
+                                           typename Prec<BF>::frag (&a)[2][3][3], typename Prec<BF>::frag (&b)[2][3],
+                                           f32x4 (&acc)[3][3][3]) {
+    typedef typename Prec<BF>::frag frag;
+    typedef typename Prec<BF>::elem elem;
+    constexpr int kM = 27 * Prec<BF>::kSub;      // MFMAs per step
+    // everything outstanding was issued at least one step ago
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int bm[3], bo[3];
 #pragma unroll
@@ -610,30 +673,31 @@ __device__ __forceinline__ void conv2_unit(const float* bufs, int mine_off, int 
         const int ng = kk < 8 ? G : (G + 1) % 3, nk = kk < 8 ? kk + 1 : 0;
         const int off = ((nk / 3) * kP2 + (nk % 3)) * 16;
         // The wave is alone on its SIMD, so whatever it issues between two MFMAs that takes longer
-        // than the 32-cycle MFMA leaves the matrix pipe idle.  The step's memory instructions are
-        // therefore dealt out one per MFMA instead of going out as a block: 3 weight loads, 9 LDS
-        // reads and, in step 0, the 13 copies of the next unit's patch (behind the operand loads,
-        // so that the wait for those - VMEM completes in order - does not have to cover the copies).
-        const int n_side = kk == 0 ? 12 + kG2Dma : 12;
+        // than the MFMA leaves the matrix pipe idle.  The step's memory instructions are therefore
+        // dealt out one per MFMA instead of going out as a block: 3 weight loads, 9 LDS reads and,
+        // in step 0, the copies of the next unit's patch (behind the operand loads, so that the
+        // wait for those - VMEM completes in order - does not have to cover the copies).
+        const int n_side = kk == 0 ? 12 + G2<BF>::kDma : 12;
+        static_assert(12 + G2<BF>::kDma <= kM, "more memory instructions than MFMAs in a step");
 #pragma unroll
-        for (int m = 0; m < 108; ++m) {
+        for (int m = 0; m < kM; ++m) {
             const int e = m / 27, t = (m / 9) % 3, j = (m / 3) % 3, nt = m % 3;
             if (G == 0 && kk == 0 && e == 0)
-                acc[t][j][nt] = mfma4(a[c][t][j][e], b[c][nt][e], f32x4{0.f, 0.f, 0.f, 0.f});
+                acc[t][j][nt] = mfma_frag<BF>(a[c][t][j], b[c][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
             else
-                acc[t][j][nt] = mfma4(a[c][t][j][e], b[c][nt][e], acc[t][j][nt]);
+                acc[t][j][nt] = mfma_frag<BF>(a[c][t][j], b[c][nt], e, acc[t][j][nt]);
             if (m < n_side) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (m < 3) {
-                    b[c ^ 1][m] = load_frag(wr, lane * 16, ng * 3072 + (nk * 9 + m) * 1024);
+                    b[c ^ 1][m] = load_frag<BF>(wr, lane, (nk * 3 + ng) * 3 + m);
                 } else if (m < 12) {
                     const int lt = (m - 3) / 3, lj = (m - 3) % 3;
-                    a[c ^ 1][lt][lj] = *reinterpret_cast<const f32x4*>(bufs + ab[lj] + off + lt * kP2 * 16);
+                    a[c ^ 1][lt][lj] = *reinterpret_cast<const frag*>(bufs + ab[lj] + off + lt * kP2 * 16);
                 } else {
                     const int it = m - 12;
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(next_src + (uint32_t)rel[it]),
-                        (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(const_cast<float*>(bufs) + other_off) + it * 1024),
+                        (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(const_cast<elem*>(bufs) + other_off) + it * 1024),
                         16, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -645,8 +709,9 @@ __device__ __forceinline__ void conv2_unit(const float* bufs, int mine_off, int 
 
 // pooled + normalised results of one wave tile -> HBM, transposed through `scratch` (3 KB of an
 // idle patch buffer) so that each pool window's 48 channels leave as 16-byte stores
+template <bool BF>
 __device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc)[3][3][3],
-                                               const float* post, const Conv2Tile& t, int Hp,
+                                               const float* post, const Conv2Tile<BF>& t, int Hp,
                                                int lane) {
     const int q = lane >> 4, ch = lane & 15;
 #pragma unroll
@@ -660,28 +725,47 @@ __device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (BF) {
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        const int f = it * 64 + lane;                 // 16-byte piece f of 16 windows x 192 bytes
-        const int win = f / 12, c4 = f % 12;
-        const int py = t.ty * 4 + (win >> 2), px = t.tx * 4 + (win & 3);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + win * kC + 4 * c4);
-        if (py < Hp && px < kW2)
-            *reinterpret_cast<f32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = v;
+        for (int it = 0; it < 2; ++it) {
+            const int f = it * 64 + lane;                 // 16-byte piece f (8 channels) of 16 windows x 96 bytes
+            const int win = min(f / 6, 15), c8 = f % 6;
+            const int py = t.ty * 4 + (win >> 2), px = t.tx * 4 + (win & 3);
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(scratch + win * kC + 8 * c8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(scratch + win * kC + 8 * c8 + 4);
+            const u32x4 v = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+            if (f < 96 && py < Hp && px < kW2)
+                *reinterpret_cast<u32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 8 * c8) = v;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int f = it * 64 + lane;                 // 16-byte piece f of 16 windows x 192 bytes
+            const int win = f / 12, c4 = f % 12;
+            const int py = t.ty * 4 + (win >> 2), px = t.tx * 4 + (win & 3);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + win * kC + 4 * c4);
+            if (py < Hp && px < kW2)
+                *reinterpret_cast<f32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = v;
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                   const float* __restrict__ wfrag,
+template <bool BF>
+__global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem* __restrict__ in,
+                                                   typename Prec<BF>::elem* __restrict__ out,
+                                                   const void* __restrict__ wfrag,
                                                    const float* __restrict__ post, int n, int Hin, int Hp,
                                                    int tiles_x, int tiles_y, int total_tiles) {
-    __shared__ __attribute__((aligned(16))) float bufs[2 * kG2BufFloats];
+    typedef typename Prec<BF>::elem elem;
+    typedef typename Prec<BF>::frag frag;
+    constexpr int kEs = Prec<BF>::kEs, kDma = G2<BF>::kDma, kBuf = G2<BF>::kBufElems;
+    __shared__ __attribute__((aligned(16))) elem bufs[2 * kBuf];
     __shared__ float spost[3 * kC];               // bias / BN scale / BN shift: read by every epilogue
     const int lane = threadIdx.x;
     const int per_frame = tiles_x * tiles_y;
-    const int64_t in_frame = (int64_t)(Hin + 2) * kP1W * kC * 4, out_frame = (int64_t)(Hp + 2) * kP2W * kC;
+    const int64_t in_frame = (int64_t)(Hin + 2) * kP1W * kC * kEs, out_frame = (int64_t)(Hp + 2) * kP2W * kC;
 
     // tile id -> is it a real tile of this batch? (the grid is rounded up to 8 frames)
     auto valid = [&](int id) {
@@ -694,9 +778,9 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
     auto locate = [&](int id) {
         int frame = 0, tt = 0;
         if (valid(id)) xcd_frame_tile(id, per_frame, frame, tt);
-        Conv2Tile t;
+        Conv2Tile<BF> t;
         t.ty = tt / tiles_x; t.tx = tt % tiles_x;
-        t.src = reinterpret_cast<const char*>(in) + frame * in_frame + ((int64_t)(12 * t.ty) * kP1W + 12 * t.tx) * kC * 4;
+        t.src = reinterpret_cast<const char*>(in) + frame * in_frame + ((int64_t)(12 * t.ty) * kP1W + 12 * t.tx) * kC * kEs;
         t.dst = out + frame * out_frame;
         return t;
     };
@@ -704,45 +788,47 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
     if (!valid(id)) return;
 
     // per-lane byte offsets of this lane's DMA pieces relative to the patch origin, group 0
-    int rel[kG2Dma];
+    int rel[kDma];
 #pragma unroll
-    for (int it = 0; it < kG2Dma; ++it) {
-        const int f = it * 64 + lane, pix = f >> 2, c4 = f & 3;
-        rel[it] = ((pix / kP2) * kP1W + pix % kP2) * kC * 4 + c4 * 16;
+    for (int it = 0; it < kDma; ++it) {
+        const int f = it * 64 + lane, pix = f / kEs, piece = f % kEs;    // kEs pieces per pixel
+        rel[it] = ((pix / kP2) * kP1W + pix % kP2) * kC * kEs + piece * 16;
     }
     const int i = lane & 15, kq = lane >> 4;
     int base[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * 16 + 4 * kq;
-    const __amdgpu_buffer_rsrc_t wr = weight_rsrc(wfrag);
+    const __amdgpu_buffer_rsrc_t wr = weight_rsrc<BF>(wfrag);
 
 #ifdef CD_DIAG
-    // diagnostic build: time stamps of the first 400 waves go to the slack frame behind the batch
+    // diagnostic build (fp32 only): time stamps of the first 400 waves go to the slack frame behind the batch
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(out + (int64_t)n * out_frame) + 32 * blockIdx.x;
     int nstamp = 0;
-#define CD_STAMP() do { if (lane == 0 && nstamp < 32 && blockIdx.x < 400) stamps[nstamp] = __builtin_amdgcn_s_memrealtime(); ++nstamp; } while (0)
+#define CD_STAMP() do { if (!BF && lane == 0 && nstamp < 32 && blockIdx.x < 400) stamps[nstamp] = __builtin_amdgcn_s_memrealtime(); ++nstamp; } while (0)
 #else
 #define CD_STAMP() do { } while (0)
 #endif
     CD_STAMP();
-    Conv2Tile cur = locate(id);
+    Conv2Tile<BF> cur = locate(id);
     int next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
-    Conv2Tile nxt = locate(next_id);
-    conv2_dma_group(cur.src, bufs, rel, lane);
+    Conv2Tile<BF> nxt = locate(next_id);
+    conv2_dma_group<BF>(cur.src, bufs, rel, lane);
     spost[lane] = post[lane];
     spost[64 + lane] = post[64 + lane];
     if (lane < 3 * kC - 128) spost[128 + lane] = post[128 + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    f32x4 a[2][3][3], b[2][3], acc[3][3][3];
-    conv2_load_step(bufs, base, wr, lane * 16, 0, 0, a[0], b[0]);
+    frag a[2][3][3], b[2][3];
+    f32x4 acc[3][3][3];
+    conv2_load_step<BF>(bufs, base, wr, lane, 0, 0, a[0], b[0]);
     CD_STAMP();
 
-    // One loop iteration = one wave tile = three units.  `first` is the buffer (as a float offset)
-    // that holds group 0 of the current tile; the look-ahead copy in the last unit puts group 0 of
-    // the next tile into the other one.
+    // One loop iteration = one wave tile = three units.  `first` is the buffer (as an element
+    // offset) that holds group 0 of the current tile; the look-ahead copy in the last unit puts
+    // group 0 of the next tile into the other one.
+    constexpr int kGroupBytes = 16 * kEs;
     int first = 0;
     for (;;) {
-        const int second = kG2BufFloats - first;
+        const int second = kBuf - first;
         // Pin step 0's operands in their registers: left to itself the compiler re-loads the
         // weights here instead of carrying them across the loop edge, and the wait for that
         // re-load would also wait (VMEM completes in order) for the patch copy issued below.
@@ -752,15 +838,15 @@ __global__ __launch_bounds__(64) void conv2_kernel(const float* __restrict__ in,
             for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(a[0][t][j]));
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) asm volatile("" : "+v"(b[0][nt]));
-        conv2_unit<0>(bufs, first, second, cur.src + 64, rel, base, wr, lane, a, b, acc);
+        conv2_unit<0, BF>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc);
         CD_STAMP();
-        conv2_unit<1>(bufs, second, first, cur.src + 128, rel, base, wr, lane, a, b, acc);
+        conv2_unit<1, BF>(bufs, second, first, cur.src + 2 * kGroupBytes, rel, base, wr, lane, a, b, acc);
         CD_STAMP();
-        conv2_unit<2>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc);
+        conv2_unit<2, BF>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc);
         CD_STAMP();
         // `first` was last read one step ago; the next tile's first unit copies into it only after
         // the epilogue's final LDS wait
-        conv2_epilogue(bufs + first, acc, spost, cur, Hp, lane);
+        conv2_epilogue<BF>(reinterpret_cast<float*>(bufs + first), acc, spost, cur, Hp, lane);
         CD_STAMP();
         if (next_id < 0) break;
         id = next_id;
@@ -785,8 +871,13 @@ int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
     const int total = (int)xcd_grid(n, tiles_x * tiles_y);
     const int grid = total < 1024 ? total : 1024;     // 4 single-wave workgroups per CU, 256 CUs
-    hipLaunchKernelGGL(conv2_kernel, dim3((unsigned)grid), dim3(64), 0, s, h->act1, h->act2, h->p.w2,
-                       h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
+    if (h->dtype == CD_BF16)
+        hipLaunchKernelGGL(conv2_kernel<true>, dim3((unsigned)grid), dim3(64), 0, s,
+                           reinterpret_cast<const uint16_t*>(h->act1), reinterpret_cast<uint16_t*>(h->act2),
+                           (const void*)h->p.w2b, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
+    else
+        hipLaunchKernelGGL(conv2_kernel<false>, dim3((unsigned)grid), dim3(64), 0, s, (const float*)h->act1, h->act2,
+                           (const void*)h->p.w2, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -802,14 +893,17 @@ int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 constexpr int kP3W = kW2 + 2;   // 30
 
+template <bool BF>
 __global__ __launch_bounds__(256) void conv3_head_kernel(
-    const float* __restrict__ in, const float* __restrict__ wfrag, const float* __restrict__ post,
+    const typename Prec<BF>::elem* __restrict__ in, const void* __restrict__ wfrag, const float* __restrict__ post,
     const float* __restrict__ fc0w, const float* __restrict__ fc0p, const float* __restrict__ fc1w,
     const float* __restrict__ fc1b, float* __restrict__ logits, float* __restrict__ maxv,
     int64_t* __restrict__ argmax, int Hin, int Hp) {
+    typedef typename Prec<BF>::elem elem;
+    constexpr int kEs = Prec<BF>::kEs;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* patch = smem;                                  // [(Hin+2)][30][48]
-    float* pooled = patch + (Hin + 2) * kP3W * kC;        // [Hp][9][48]
+    elem* patch = reinterpret_cast<elem*>(smem);          // [(Hin+2)][30][48]
+    float* pooled = smem + (Hin + 2) * kP3W * kC * kEs / 4;   // [Hp][9][48]
     float* feat = pooled + Hp * kW3 * kC;                 // [768]
     float* hid = feat + kFeat;                            // [32]
     const int tid = threadIdx.x;
@@ -820,16 +914,16 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
 
 #ifdef CD_DIAG
     // diagnostic build: per-wave time stamps go to the slack frame behind the batch's activations
-    unsigned long long* st3 = reinterpret_cast<unsigned long long*>(const_cast<float*>(in) + (int64_t)gridDim.x * (Hin + 2) * kP3W * kC) + (blockIdx.x * 4 + wave) * 8;
+    unsigned long long* st3 = reinterpret_cast<unsigned long long*>(const_cast<elem*>(in) + (int64_t)gridDim.x * (Hin + 2) * kP3W * kC) + (blockIdx.x * 4 + wave) * 8;
     int nst3 = 0;
-#define CD_STAMP3() do { if (lane == 0 && blockIdx.x < 400) st3[nst3] = __builtin_amdgcn_s_memrealtime(); ++nst3; } while (0)
+#define CD_STAMP3() do { if (!BF && lane == 0 && blockIdx.x < 400) st3[nst3] = __builtin_amdgcn_s_memrealtime(); ++nst3; } while (0)
 #else
 #define CD_STAMP3() do { } while (0)
 #endif
     CD_STAMP3();
     // the padded block-2 activation of this frame is contiguous in HBM: a linear LDS-DMA copy
     const char* fin = reinterpret_cast<const char*>(in + (int64_t)frame * (Hin + 2) * kP3W * kC);
-    const int patch_bytes = (Hin + 2) * kP3W * kC * 4;
+    const int patch_bytes = (Hin + 2) * kP3W * kC * kEs;
     for (int off0 = (tid >> 6) * 1024; off0 < patch_bytes; off0 += 4096) {
         const int off = off0 + (tid & 63) * 16;
         if (off < patch_bytes)
@@ -876,7 +970,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
         f32x4 acc[3][3][3];
         // columns of one lane's 12 may straddle pool rows here, so tile (t, j) of lane-row i uses
         // base[j] for every t and the conv row offset t is applied inside the tile routine
-        conv48_wave_tile<kP3W>(patch, base, weight_rsrc(wfrag), lane * 16, acc);
+        conv48_wave_tile<kP3W, BF>(patch, base, weight_rsrc<BF>(wfrag), lane, acc);
         CD_STAMP3();
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
@@ -950,21 +1044,29 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
 // The head kernel needs more dynamic LDS than the default limit; the limit is a per-device
 // attribute of the kernel, so this runs once per handle with the handle's device current.
 int init_conv3_head() {
-    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel),
+    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     return CD_OK;
 }
 
 int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logits, float* maxv,
                       int64_t* argmax, hipStream_t s) {
-    const size_t lds = head_lds_bytes(g);
+    const bool bf = h->dtype == CD_BF16;
+    const size_t lds = head_lds_bytes(g, bf ? 2 : 4);
     if (lds > (size_t)kLdsBytes) {
         set_error("network input of %d rows needs %zu bytes of LDS in the head kernel (max %d)", g.h, lds, kLdsBytes);
         return CD_EINVAL;
     }
-    hipLaunchKernelGGL(conv3_head_kernel, dim3((unsigned)n), dim3(256), lds, s, h->act2, h->p.w3,
-                       h->p.post + 6 * kC, h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax,
-                       g.h2, g.h3);
+    if (bf)
+        hipLaunchKernelGGL(conv3_head_kernel<true>, dim3((unsigned)n), dim3(256), lds, s,
+                           reinterpret_cast<const uint16_t*>(h->act2), (const void*)h->p.w3b, h->p.post + 6 * kC,
+                           h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3);
+    else
+        hipLaunchKernelGGL(conv3_head_kernel<false>, dim3((unsigned)n), dim3(256), lds, s, (const float*)h->act2,
+                           (const void*)h->p.w3, h->p.post + 6 * kC, h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b,
+                           logits, maxv, argmax, g.h2, g.h3);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }

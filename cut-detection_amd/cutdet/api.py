@@ -17,12 +17,12 @@ def default_blob():
         return f.read()
 
 
-def default_engine(device="cuda:0"):
-    """The Engine holding the bundled prod_net on `device` (created on first use)."""
+def default_engine(device="cuda:0", dtype="f32"):
+    """The Engine holding the bundled prod_net on `device` in `dtype` arithmetic (created on first use)."""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError(f"cutdet has no CPU path; asked for device {device!r}")
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx not in _engines:
-        _engines[idx] = Engine(default_blob(), torch.device("cuda", idx))
-    return _engines[idx]
+    if (idx, dtype) not in _engines:
+        _engines[(idx, dtype)] = Engine(default_blob(), torch.device("cuda", idx), dtype)
+    return _engines[(idx, dtype)]

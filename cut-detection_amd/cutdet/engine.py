@@ -25,7 +25,12 @@ def _ptr(t):
 class Engine:
     """One classifier instance on one GPU."""
 
-    def __init__(self, blob, device="cuda:0"):
+    def __init__(self, blob, device="cuda:0", dtype="f32"):
+        """dtype "f32": the reference's arithmetic.  "bf16": blocks 2 and 3 on the bf16 matrix cores
+        with fp32 accumulation (logits move by about 1e-2; outputs stay fp32 tensors)."""
+        if dtype not in _lib.DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(_lib.DTYPES)}, got {dtype!r}")
+        self.dtype = dtype
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("cutdet.Engine runs on an MI355X only; got device %r (no CPU fallback)" % (device,))
@@ -35,7 +40,7 @@ class Engine:
         self.device = torch.device("cuda", index)
         self._blob = bytes(blob)
         self._h = C.c_void_p(0)
-        check(lib.cd_create(C.byref(self._h), self._blob, len(self._blob), index, _lib.CD_F32))
+        check(lib.cd_create(C.byref(self._h), self._blob, len(self._blob), index, _lib.DTYPES[dtype]))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

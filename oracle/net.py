@@ -90,6 +90,35 @@ def forward(w, x):
     return forward_layers(w, x)[-1]
 
 
+def _bf16(t):
+    """Round to bfloat16 (nearest even) and back: the values a bf16 matrix-core operand holds."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def forward_bf16(w, x):
+    """Restatement of the bf16 mode of the GPU library (no counterpart in the reference, which is
+    fp32 only): block 1 in fp32; its output and the block-2 output are rounded to bfloat16 where the
+    GPU stores them, the block-2/3 weights are rounded to bfloat16, products are exact and sums are
+    fp32; everything from the block-3 epilogue on is fp32.  Differences from the GPU are summation
+    order only - but a sum that lands near a bf16 rounding boundary can round the other way, so
+    agreement is to a few bf16 ulps of the activations, not to fp32 round-off."""
+    if not torch.is_tensor(x):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    with torch.no_grad():
+        for l in range(w["_meta"]["conv_layers"]):
+            wt = w[f"c{l}.w"] if l == 0 else _bf16(w[f"c{l}.w"])
+            x = F.conv2d(x, wt, w[f"c{l}.b"], padding=1)
+            x = F.relu(x)
+            x = F.max_pool2d(x, kernel_size=3)
+            x = _bn(x, w, f"c{l}")
+            if l < 2:
+                x = _bf16(x)
+        x = F.adaptive_avg_pool2d(x, w["_meta"]["avg_pool"])
+        x = x.reshape(x.shape[0], -1)
+        x = _bn(F.relu(F.linear(x, w["fc0.w"], w["fc0.b"])), w, "fc0")
+        return F.linear(x, w["fc1.w"], w["fc1.b"])
+
+
 class _Net(torch.nn.Module):
     def __init__(self, w):
         super().__init__()

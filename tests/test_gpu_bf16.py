@@ -1,0 +1,104 @@
+"""bf16 mode of the HIP path (blocks 2 and 3 on the bf16 matrix cores, fp32 accumulation).
+
+The reference computes in fp32 only, so this mode has no reference fixture: "parity unpinned" beyond
+what follows.  It is held to (a) the oracle's restatement of the same arithmetic
+(oracle.net.forward_bf16: identical rounding points, fp32 sums in another order), within 2e-3 -
+measured 1e-4..2e-4, the slack covers a sum landing across a bf16 rounding boundary; (b) the pinned
+fp32 oracle within 6e-2 on logits of magnitude 5-40 (measured 1.7e-2..3.4e-2: bf16 keeps 8 mantissa
+bits of each activation); (c) class ids, segment tables and CSV bytes identical to the fp32 chain on
+the synthetic clips, whose class margins (>= 2.4) dwarf that error.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SEED = 1234
+TOL_SAME_ARITHMETIC = 2e-3
+TOL_VS_FP32 = 6e-2
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from cutdet import api
+    return api.default_engine("cuda:0"), api.default_engine("cuda:0", "bf16")
+
+
+@pytest.fixture(scope="module")
+def oracle_weights():
+    from oracle import net as onet
+    return onet.load_blob()
+
+
+@pytest.mark.parametrize("h,w,n", [(720, 1280, 24), (1080, 1920, 12), (180, 320, 24), (480, 640, 9)])
+def test_bf16_forward_u8_matches_its_restatement_and_fp32(engines, oracle_weights, h, w, n):
+    from oracle import net as onet
+    e32, e16 = engines
+    classes = torch.tensor([i % 3 for i in range(n)], dtype=torch.uint8, device=e32.device)
+    frames = e32.synth_frames(classes, h, w, SEED)
+    l16, m16, c16 = e16.forward_u8(frames)
+    x = e32.preprocess(frames).cpu()          # bit-exact against the oracle's resize elsewhere in the suite
+    ref16 = onet.forward_bf16(oracle_weights, x)
+    ref32 = onet.forward(oracle_weights, x)
+    assert float((l16.cpu() - ref16).abs().max()) <= TOL_SAME_ARITHMETIC
+    assert float((l16.cpu() - ref32).abs().max()) <= TOL_VS_FP32
+    assert c16.cpu().tolist() == ref32.argmax(1).tolist() == classes.cpu().tolist()
+    mx, am = torch.max(l16, 1)
+    assert torch.equal(mx, m16) and torch.equal(am, c16)
+
+
+def test_bf16_float_entry_and_odd_heights(engines, oracle_weights):
+    from oracle import net as onet
+    _, e16 = engines
+    g = torch.Generator().manual_seed(7)
+    for h in (27, 100, 144, 215):
+        x = torch.rand((5, 3, h, 256), generator=g)
+        got = e16.forward(x.to(e16.device)).cpu()
+        assert float((got - onet.forward_bf16(oracle_weights, x)).abs().max()) <= TOL_SAME_ARITHMETIC
+
+
+def test_bf16_clip_1080p_segments_identical_to_fp32_chain(engines):
+    """The 1080p bf16 configuration: logits move, class ids, segments and CSV do not."""
+    from cutdet import synth as csynth
+    from cutdet.pipeline import ClipClassifier
+    e32, e16 = engines
+    n = 1536
+    runs = csynth.run_table(n, SEED)
+    cl = csynth.classes_from_runs(runs)
+    frames = e32.synth_frames(torch.tensor(cl, dtype=torch.uint8, device=e32.device), 1080, 1920, SEED)
+    out = []
+    for eng in (e32, e16):
+        clip = ClipClassifier(eng, n)
+        for a in range(0, n, 512):
+            clip.classify(frames[a:a + 512], a)
+        out.append((clip.cls.cpu().tolist(), clip.logits.cpu(), clip.segment()))
+    (c32, l32, s32), (c16, l16, s16) = out
+    assert c16 == c32 == cl
+    assert float((l16 - l32).abs().max()) <= TOL_VS_FP32
+    for k in ("end_frames", "frame_types", "run_lengths", "start_frames"):
+        assert s16["merged"][k].tolist() == s32["merged"][k].tolist()
+    assert s16["csv"] == s32["csv"]
+
+
+def test_bf16_is_deterministic_and_handles_are_independent(engines):
+    e32, e16 = engines
+    frames = e32.synth_frames(torch.tensor([0, 1, 2] * 11, dtype=torch.uint8, device=e32.device), 720, 1280, 3)
+    a = e16.forward_u8(frames)[0].clone()
+    b32 = e32.forward_u8(frames)[0].clone()      # the other handle's workspace is untouched by this
+    assert torch.equal(a, e16.forward_u8(frames)[0])
+    assert torch.equal(b32, e32.forward_u8(frames)[0])
+    assert not torch.equal(a, b32)
+
+
+def test_create_rejects_unknown_dtype():
+    from cutdet import _lib, api
+    h = C.c_void_p(0)
+    blob = api.default_blob()
+    rc = _lib.lib.cd_create(C.byref(h), blob, len(blob), 0, 2)
+    assert rc == _lib.CD_EINVAL and b"dtype" in _lib.lib.cd_last_error()
+    with pytest.raises(ValueError):
+        from cutdet.engine import Engine
+        Engine(blob, "cuda:0", dtype="fp8")

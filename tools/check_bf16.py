@@ -1,0 +1,34 @@
+"""Quick check of the bf16 mode against the oracle's bf16 restatement and the fp32 path."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cut-detection_amd")); sys.path.insert(0, ROOT)
+import numpy as np, torch
+from cutdet import api
+from oracle import net as onet, preprocess as opre
+e32 = api.default_engine("cuda:0"); e16 = api.default_engine("cuda:0", "bf16")
+w = onet.load_blob()
+for (H0, W0, n) in ((720, 1280, 24), (180, 320, 24), (1080, 1920, 12)):
+    classes = torch.tensor([i % 3 for i in range(n)], dtype=torch.uint8, device="cuda")
+    frames = e32.synth_frames(classes, H0, W0, 1234)
+    l32, _, c32 = e32.forward_u8(frames)
+    l16, m16, c16 = e16.forward_u8(frames)
+    x = e32.preprocess(frames)
+    ref16 = onet.forward_bf16(w, x.cpu())
+    ref32 = onet.forward(w, x.cpu())
+    print(f"{W0}x{H0}: |bf16 gpu - bf16 oracle| max {float((l16.cpu() - ref16).abs().max()):.3e}   "
+          f"|bf16 gpu - fp32 oracle| max {float((l16.cpu() - ref32).abs().max()):.3e}   "
+          f"|fp32 gpu - fp32 oracle| max {float((l32.cpu() - ref32).abs().max()):.3e}   classes equal: {bool((c16 == c32).all())}")
+# fp32 NCHW entry in bf16 mode
+x = torch.rand(8, 3, 144, 256, device="cuda")
+print("forward(): max diff vs bf16 oracle %.3e" % float((e16.forward(x)[0].cpu() - onet.forward_bf16(w, x.cpu())).abs().max()))
+import time
+frames = e32.synth_frames(torch.zeros(256, dtype=torch.uint8, device="cuda"), 720, 1280, 1)
+for eng, nm in ((e32, "f32"), (e16, "bf16")):
+    for _ in range(5): eng.forward_u8(frames)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20): eng.forward_u8(frames)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
+    eng.timing_enable(True)
+    for _ in range(10): eng.forward_u8(frames)
+    tm = eng.timing_read(); eng.timing_enable(False)
+    print(nm, "%.1f us per 256-frame batch -> %.0f frames/s;" % (dt * 1e6, 256 / dt), {k: round(v[1] / max(1, v[0]) * 1e3, 1) for k, v in tm.items() if v[0]})
