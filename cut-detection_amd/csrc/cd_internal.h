@@ -70,6 +70,7 @@ struct DeviceParams {
     float* w1;    // conv1: [9 pieces][64 lanes][4]: B fragments (pieces 0-5), bias / BN scale / BN shift (6-8)
     float* w2;    // conv2 B fragments  [27 steps][3 n-tiles][64 lanes][4]
     float* w3;    // conv3 B fragments  (same layout as w2)
+    uint16_t* w1b;  // conv1 B fragments in bf16: [3 ky][3 n-tiles][64 lanes][4] (kx = lane>>4, channel e; zero pads)
     uint16_t* w2b;  // conv2 / conv3 B fragments in bf16: [27 steps][3 n-tiles][64 lanes][4]
     uint16_t* w3b;
     float* post;  // [3 layers][3][48]: conv bias, BN scale, BN shift

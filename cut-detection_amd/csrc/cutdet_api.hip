@@ -39,7 +39,7 @@ void bn_affine(const float* g, const float* beta, const float* mu, const float* 
     }
 }
 
-struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b; };
+struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b, w1b; };
 
 // float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 and torch's .bfloat16() do)
 static uint16_t bf16_rne(float f) {
@@ -117,6 +117,19 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
         uint16_t* d = reinterpret_cast<uint16_t*>(&img[dst]);
         for (size_t k = 0; k < (size_t)27 * 3 * 64 * 4; ++k) d[k] = bf16_rne(img[src + k]);
     }
+    // block 1 in bf16: fragment (ky, nt), lane (kx = lane>>4, col): W[16nt+col][ci = e][ky][kx], zero for kx = 3 / e = 3
+    const size_t o_w1b = section(9 * 64 * 2);
+    {
+        uint16_t* d = reinterpret_cast<uint16_t*>(&img[o_w1b]);
+        for (int ky = 0; ky < 3; ++ky)
+            for (int nt = 0; nt < 3; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int kx = lane >> 4, oc = 16 * nt + (lane & 15);
+                        const float v = (kx < 3 && e < 3) ? cv[0].w[oc * 27 + e * 9 + ky * 3 + kx] : 0.f;
+                        d[((ky * 3 + nt) * 64 + lane) * 4 + e] = bf16_rne(v);
+                    }
+    }
     for (int l = 0; l < 3; ++l) {
         float* p = &img[o_post + (size_t)l * 3 * kC];
         std::memcpy(p, cv[l].b, kC * sizeof(float));
@@ -135,7 +148,7 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     std::memcpy(&img[o_fc1b], fc1b, kOut * sizeof(float));
     for (int k = 0; k < 256; ++k) img[o_lut + k] = (float)k / 255.0f;   // data.py:227 divides, it does not scale
 
-    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b};
+    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b, o_w1b};
     return img;
 }
 
@@ -319,6 +332,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->p.w1 = base + off.w1; h->p.w2 = base + off.w2; h->p.w3 = base + off.w3; h->p.post = base + off.post;
     h->p.fc0w = base + off.fc0w; h->p.fc0p = base + off.fc0p; h->p.fc1w = base + off.fc1w;
     h->p.fc1b = base + off.fc1b; h->p.lut = base + off.lut;
+    h->p.w1b = reinterpret_cast<uint16_t*>(base + off.w1b);
     h->p.w2b = reinterpret_cast<uint16_t*>(base + off.w2b); h->p.w3b = reinterpret_cast<uint16_t*>(base + off.w3b);
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);

@@ -187,7 +187,16 @@ __device__ __forceinline__ void put_pixel(float* tile, int r, int c, uint32_t px
     tile[(2 * kC1Rows + r) * kC1RS + c] = bgr ? f0 : f2;
 }
 
-__device__ __forceinline__ void point_commit(float* tile, int tid, PointRaw& raw, const PointCol& c, bool bgr) {
+// bf16 tile of the bf16 block-1 kernel: one 8-byte cell per pixel, {R, G, B, 0} in bfloat16
+constexpr int kC1RSB = 260;       // its row stride in pixels (columns -1 .. 256 used)
+__device__ __forceinline__ void put_pixel(uint2* tile, int r, int c, uint32_t px, bool bgr) {
+    const float f0 = byte_to_unit((float)(px & 255u)), f1 = byte_to_unit((float)((px >> 8) & 255u)),
+                f2 = byte_to_unit((float)((px >> 16) & 255u));
+    tile[r * kC1RSB + c] = uint2{pack_bf16(bgr ? f2 : f0, f1), pack_bf16(bgr ? f0 : f2, 0.f)};
+}
+
+template <typename T>
+__device__ __forceinline__ void point_commit(T* tile, int tid, PointRaw& raw, const PointCol& c, bool bgr) {
     // (each row's conversion is pinned behind the previous row's LDS writes: scheduled freely, the
     // conversions of all 36 values are hoisted to where the loads were issued and spill)
 #pragma unroll
@@ -205,7 +214,8 @@ __device__ __forceinline__ void point_commit(float* tile, int tid, PointRaw& raw
 // loads of a column are in flight before the first is used.  Arithmetic as sample_u8().
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 
-__device__ __forceinline__ void generic_stage(float* tile, const uint8_t* __restrict__ fsrc,
+template <typename T>
+__device__ __forceinline__ void generic_stage(T* tile, const uint8_t* __restrict__ fsrc,
                                               const SampleArgs& sa, int gy0, int H, int tid, bool bgr) {
     const int last = sa.W0 * 3 - 8;            // last byte offset an 8-byte load may start at
     for (int c = tid; c < 257; c += 256) {
@@ -480,6 +490,122 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Block 1 in bf16 mode: the same workgroup / wave-tile / epilogue structure, on
+// v_mfma_f32_16x16x16_bf16.  The LDS tile holds one 8-byte cell {R, G, B, 0} per pixel, so the A
+// fragment of conv row ky - K slots 4kq + e = (kx = kq, channel e), kq = 3 and e = 3 carrying zero
+// weights - is one 8-byte LDS read at pixel (row + ky, col + kq): K = 27 goes through three MFMAs
+// instead of seven, with no packing instructions.  The 15 fragments of a wave tile (5 tile rows x 3
+// column groups) are read once and serve all 81 of its MFMAs.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void f32_stage_bf16(uint2* tile, const float* __restrict__ fx, int gy0, int H, int tid) {
+    for (int idx = tid; idx < kC1Rows * 258; idx += 256) {
+        const int c = idx % 258, r = idx / 258;
+        const int gy = gy0 + r, gx = c - 1;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < kNetW)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) v[ci] = fx[((int64_t)ci * H + gy) * kNetW + gx];
+        tile[r * kC1RSB + c] = uint2{pack_bf16(v[0], v[1]), pack_bf16(v[2], 0.f)};
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void conv1_bf16_kernel(
+    const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
+    int chan_order, const bf16x4* __restrict__ wfrag, const float* __restrict__ post, uint16_t* __restrict__ out,
+    int n, int H, int Hp, int chunks) {
+    __shared__ __attribute__((aligned(16))) uint2 tile[kC1Rows * kC1RSB];
+    __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];   // per-wave 16x16 transposes
+    __shared__ float spost[3 * kC];
+    const int tid = threadIdx.x;
+    int frame, chunk;
+    xcd_frame_tile(blockIdx.x, chunks, frame, chunk);
+    if (frame >= n) return;
+    const bool bgr = chan_order == CD_BGR;
+    const uint8_t* fsrc = MODE != 0 ? src + (int64_t)frame * frame_stride : nullptr;
+    const float* fx = MODE == 0 ? x + (int64_t)frame * kInC * H * kNetW : nullptr;
+    const int py0 = chunk * kC1PoolRows;
+    const int gy0 = 3 * py0 - 1;            // input row held in tile row 0
+
+    PointRaw raw;
+    PointCol pcol{};
+    if (MODE == 1) {
+        pcol = point_columns(sa, tid);
+#pragma unroll
+        for (int u = 0; u < kC1Rows + 1; ++u) raw.v[u] = point_fetch_piece(fsrc, sa, pcol, gy0, H, tid, u);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int q = lane >> 4, ch = lane & 15;
+    uint16_t* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
+    float* my_out = scratch + wave * 256;
+    // B fragments (ky, n-tile) stay in registers; bias and BatchNorm terms go to LDS
+    bf16x4 bw[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) bw[ky][nt] = wfrag[(ky * 3 + nt) * 64 + lane];
+    if (tid < 3 * kC) spost[tid] = post[tid];
+
+    if (MODE == 0) f32_stage_bf16(tile, fx, gy0, H, tid);
+    else if (MODE == 1) point_commit(tile, tid, raw, pcol, bgr);
+    else generic_stage(tile, fsrc, sa, gy0, H, tid, bgr);
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {            // wave tile wt = wave + 4k
+        int wt = wave + 4 * k;
+        asm volatile("" : "+v"(wt));         // keeps the compiler from hoisting all four tiles' addresses
+        // tile cell of the pixel that A-row i of column group j maps to, shifted by this lane's kx
+        int base[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c12 = 4 * j + (i & 3), d = (c12 * 11) >> 5, m = c12 - 3 * d;   // d = c12 / 3
+            const int W = min(16 * wt + 4 * (i >> 2) + d, kC1Windows - 1);
+            const int wr = (W >= kW1 ? 1 : 0) + (W >= 2 * kW1 ? 1 : 0);               // W / 85
+            // (lanes kq = 3 carry zero weights; they re-read the kq = 2 cell, which is always written:
+            // a never-written LDS cell may hold a NaN pattern, and NaN x 0 would poison the sum)
+            base[j] = 3 * wr * kC1RSB + 3 * (W - wr * kW1) + m + min(kq, 2);
+        }
+        const int Ws = 16 * wt + (lane >> 2);
+        const int wrs = (Ws >= kW1 ? 1 : 0) + (Ws >= 2 * kW1 ? 1 : 0);
+        const bool st_ok = Ws < kC1Windows && py0 + wrs < Hp;
+        uint16_t* st_ptr = fout + ((int64_t)(py0 + wrs + 1) * kP1W + (Ws - wrs * kW1) + 1) * kC + 4 * (lane & 3);
+        bf16x4 a[5][3];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[r][j] = __builtin_bit_cast(bf16x4, tile[base[j] + r * kC1RSB]);
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const float bias = spost[nt * 16 + ch];
+            const f32x4 bias4 = f32x4{bias, bias, bias, bias};
+            f32x4 acc[3][3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[t + ky][j], bw[ky][nt],
+                                                                               ky == 0 ? bias4 : acc[t][j], 0, 0, 0);
+            const float sc = spost[kC + nt * 16 + ch], sh = spost[2 * kC + nt * 16 + ch];
+            float m[4] = {window_max<0>(acc), window_max<1>(acc), window_max<2>(acc), window_max<3>(acc)};
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) my_out[(4 * q + wi) * 16 + ch] = fmaf(m[wi], sc, sh);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + (lane >> 2) * 16 + 4 * (lane & 3));
+                if (st_ok) *reinterpret_cast<uint2*>(st_ptr + nt * 16) = uint2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read done before the next group rewrites
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 static unsigned xcd_grid(int n, int per_frame) { return (unsigned)(((n + 7) / 8) * 8 * per_frame); }
 
 // Chunks per workgroup: as many as still leave four workgroups for every CU (the most that fit),
@@ -494,8 +620,9 @@ static void launch_conv1(const cd_handle* h, unsigned grid, hipStream_t s, const
                          const SampleArgs& sa, int64_t frame_stride, int chan_order, int n, const Geometry& g,
                          int chunks, int groups, int cpw) {
     if (h->dtype == CD_BF16)
-        hipLaunchKernelGGL((conv1_kernel<MODE, true>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
-                           (const float*)h->p.w1, reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw);
+        hipLaunchKernelGGL((conv1_bf16_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), 0, s, x, src, sa, frame_stride,
+                           chan_order, reinterpret_cast<const bf16x4*>(h->p.w1b), (const float*)h->p.post,
+                           reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks);
     else
         hipLaunchKernelGGL((conv1_kernel<MODE, false>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
                            (const float*)h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw);
@@ -599,6 +726,9 @@ __device__ __forceinline__ void conv48_wave_tile(const typename Prec<BF>::elem* 
 // issued after a DMA also covers that DMA; the explicit vmcnt(0) at each group boundary (where
 // only loads issued a full step earlier are outstanding) makes that ordering unconditional.
 // ------------------------------------------------------------------------------------------
+#ifndef CD_C2_BF16_WAVES
+#define CD_C2_BF16_WAVES 2048
+#endif
 constexpr int kP2 = 14;
 constexpr int kG2Pix = kP2 * kP2;              // 196 pixels
 // per precision: 16-byte pieces of one channel group of a patch (16 channels x element size per
@@ -870,7 +1000,11 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
 int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
     const int total = (int)xcd_grid(n, tiles_x * tiles_y);
-    const int grid = total < 1024 ? total : 1024;     // 4 single-wave workgroups per CU, 256 CUs
+    // persistent single-wave workgroups: one per SIMD in fp32 (the wave needs 308 registers and keeps
+    // the matrix pipe busy on its own), two per SIMD in bf16 (the MFMAs are 4x shorter, so a second
+    // wave has to cover the first one's LDS and epilogue latencies)
+    const int cap = h->dtype == CD_BF16 ? CD_C2_BF16_WAVES : 1024;
+    const int grid = total < cap ? total : cap;
     if (h->dtype == CD_BF16)
         hipLaunchKernelGGL(conv2_kernel<true>, dim3((unsigned)grid), dim3(64), 0, s,
                            reinterpret_cast<const uint16_t*>(h->act1), reinterpret_cast<uint16_t*>(h->act2),

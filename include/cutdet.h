@@ -46,9 +46,10 @@ enum {
 };
 
 /* Arithmetic type of the forward pass.  CD_F32: everything in fp32 (what the reference computes).
- * CD_BF16: blocks 2 and 3 multiply bfloat16 activations and weights on the bf16 matrix cores with
- * fp32 accumulation; block 1, the pooling/affine epilogues and the head stay fp32.  Logits then
- * differ from the fp32 result by about 1e-2; class ids are unchanged on inputs with clear margins. */
+ * CD_BF16: the three convolutions multiply bfloat16 inputs/activations and weights on the bf16
+ * matrix cores with fp32 accumulation; bias, pooling/affine epilogues and the head stay fp32.
+ * Logits then differ from the fp32 result by a few 1e-2; class ids are unchanged on inputs with
+ * clear margins. */
 enum { CD_F32 = 0, CD_BF16 = 1 };
 enum { CD_BGR = 0, CD_RGB = 1 };         /* channel order of u8 frames in memory */
 

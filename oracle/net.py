@@ -97,17 +97,19 @@ def _bf16(t):
 
 def forward_bf16(w, x):
     """Restatement of the bf16 mode of the GPU library (no counterpart in the reference, which is
-    fp32 only): block 1 in fp32; its output and the block-2 output are rounded to bfloat16 where the
-    GPU stores them, the block-2/3 weights are rounded to bfloat16, products are exact and sums are
-    fp32; everything from the block-3 epilogue on is fp32.  Differences from the GPU are summation
-    order only - but a sum that lands near a bf16 rounding boundary can round the other way, so
-    agreement is to a few bf16 ulps of the activations, not to fp32 round-off."""
+    fp32 only): the network input, the outputs of blocks 1 and 2 and all conv weights are rounded
+    to bfloat16 where the GPU stores them; products are exact and sums are fp32; bias, ReLU,
+    pooling, BatchNorm affine and everything from the block-3 epilogue on are fp32.  Differences
+    from the GPU are summation order only - but a sum that lands near a bf16 rounding boundary can
+    round the other way, so agreement is to a few bf16 ulps of the activations, not to fp32
+    round-off."""
     if not torch.is_tensor(x):
         x = torch.from_numpy(np.ascontiguousarray(x))
     with torch.no_grad():
         for l in range(w["_meta"]["conv_layers"]):
-            wt = w[f"c{l}.w"] if l == 0 else _bf16(w[f"c{l}.w"])
-            x = F.conv2d(x, wt, w[f"c{l}.b"], padding=1)
+            if l == 0:
+                x = _bf16(x)
+            x = F.conv2d(x, _bf16(w[f"c{l}.w"]), w[f"c{l}.b"], padding=1)
             x = F.relu(x)
             x = F.max_pool2d(x, kernel_size=3)
             x = _bn(x, w, f"c{l}")

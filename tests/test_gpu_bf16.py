@@ -1,12 +1,13 @@
-"""bf16 mode of the HIP path (blocks 2 and 3 on the bf16 matrix cores, fp32 accumulation).
+"""bf16 mode of the HIP path (the three convolutions on the bf16 matrix cores, fp32 accumulation).
 
 The reference computes in fp32 only, so this mode has no reference fixture: "parity unpinned" beyond
 what follows.  It is held to (a) the oracle's restatement of the same arithmetic
-(oracle.net.forward_bf16: identical rounding points, fp32 sums in another order), within 2e-3 -
-measured 1e-4..2e-4, the slack covers a sum landing across a bf16 rounding boundary; (b) the pinned
-fp32 oracle within 6e-2 on logits of magnitude 5-40 (measured 1.7e-2..3.4e-2: bf16 keeps 8 mantissa
-bits of each activation); (c) class ids, segment tables and CSV bytes identical to the fp32 chain on
-the synthetic clips, whose class margins (>= 2.4) dwarf that error.
+(oracle.net.forward_bf16: identical rounding points, fp32 sums in another order), within 5e-3 -
+measured 3e-4..1.9e-3: a sum that lands across a bf16 rounding boundary moves one activation by a
+bf16 ulp; (b) the pinned fp32 oracle within 8e-2 on logits of magnitude 5-40 (measured
+3.7e-2..4.2e-2: bf16 keeps 8 mantissa bits of every input and activation); (c) class ids, segment
+tables and CSV bytes identical to the fp32 chain on the synthetic clips, whose class margins
+(>= 2.4) dwarf that error.
 """
 import ctypes as C
 
@@ -17,8 +18,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SEED = 1234
-TOL_SAME_ARITHMETIC = 2e-3
-TOL_VS_FP32 = 6e-2
+TOL_SAME_ARITHMETIC = 5e-3
+TOL_VS_FP32 = 8e-2
 
 
 @pytest.fixture(scope="module")

@@ -20,7 +20,7 @@ for (H0, W0, n) in ((720, 1280, 24), (180, 320, 24), (1080, 1920, 12)):
           f"|fp32 gpu - fp32 oracle| max {float((l32.cpu() - ref32).abs().max()):.3e}   classes equal: {bool((c16 == c32).all())}")
 # fp32 NCHW entry in bf16 mode
 x = torch.rand(8, 3, 144, 256, device="cuda")
-print("forward(): max diff vs bf16 oracle %.3e" % float((e16.forward(x)[0].cpu() - onet.forward_bf16(w, x.cpu())).abs().max()))
+print("forward(): max diff vs bf16 oracle %.3e" % float((e16.forward(x).cpu() - onet.forward_bf16(w, x.cpu())).abs().max()))
 import time
 frames = e32.synth_frames(torch.zeros(256, dtype=torch.uint8, device="cuda"), 720, 1280, 1)
 for eng, nm in ((e32, "f32"), (e16, "bf16")):
