@@ -41,8 +41,17 @@ FLOPS_CONV2 = 2 * 48 * 85 * 48 * 432
 FLOPS_CONV3 = 2 * 16 * 28 * 48 * 432
 FLOPS_FC = 2 * (768 * 32 + 32 * 3)
 FLOPS_FRAME = FLOPS_CONV1 + FLOPS_CONV2 + FLOPS_CONV3 + FLOPS_FC          # 283 386 048
-BYTES_FRAME_720P = 144 * 1280 * 3 + 12                                      # sampled source rows + logits
+
+
+def compulsory_bytes(h0, w0, net_h):
+    """Source rows the resize actually samples x row bytes + 12 B of logits (552 972 B at 720p: an odd
+    integer scale is a pure point sample, anything else touches two source rows per output row)."""
+    point = h0 % net_h == 0 and (h0 // net_h) % 2 == 1
+    return min(h0, net_h if point else 2 * net_h) * w0 * 3 + 12
+
+
 PEAK_F32_MFMA_TFLOPS = 157.3                                                # dense fp32 matrix peak, MI355X
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                              # dense bf16 matrix peak (--dtype bf16 only)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -55,6 +64,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--height", type=int, default=H0, help="source frame height (default: the 720p headline)")
     ap.add_argument("--width", type=int, default=W0, help="source frame width")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 is the headline (the reference's arithmetic); bf16 runs the library's bf16 mode, "
+                         "whose logits differ by a few 1e-2 - a separate, non-headline measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-timing", choices=["dominant", "all", "off"], default="dominant",
                     help="which kernels are bracketed with HIP events inside the timed region: the dominant "
@@ -130,7 +142,8 @@ def main():
     from cutdet import api, synth as csynth
     from cutdet.pipeline import ClipClassifier
 
-    eng = api.default_engine(dev)
+    eng = api.default_engine(dev, args.dtype)
+    peak_tflops = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     n_clip, bs = args.clip_frames, args.batch
     # this rank's contiguous frame range of the (world * n_clip)-frame game
     runs = csynth.run_table(world * n_clip, SEED)
@@ -138,7 +151,7 @@ def main():
     first = rank * n_clip
     classes = torch.tensor(classes_all[first:first + n_clip], dtype=torch.uint8, device=dev)
     frames = eng.synth_frames(classes, args.height, args.width, SEED, first_index=first)   # u8 clip in HBM
-    eng.reserve(bs, NET_H)
+    eng.reserve(bs, int(args.height * (256 / args.width)))
     clip = ClipClassifier(eng, n_clip)
     batches = [(a, min(n_clip, a + bs)) for a in range(0, n_clip, bs)]
     group = dist.group.WORLD if world > 1 else None
@@ -210,26 +223,30 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         fps = total_frames / dt_max
+        net_h = int(args.height * (256 / args.width))
+        bytes_frame = compulsory_bytes(args.height, args.width, net_h)
+        if args.dtype != "f32" or (args.height, args.width) != (H0, W0):
+            traffic = None          # the committed PMC figure is of the fp32 720p kernel
         out = {
-            "metric": "frames/sec classified+segmented, 1280x720 RGB",
+            "metric": f"frames/sec classified+segmented, {args.width}x{args.height} RGB",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{n_clip} synthetic {args.width}x{args.height} u8 frames per GPU resident in HBM, batch={bs}, "
-                                   "fp32 prod_net, fused resize+classify, GPU run-length encode, host glue/merge, CSV",
+                                   f"{'fp32' if args.dtype == 'f32' else 'bf16-matrix-core'} prod_net, fused resize+classify, GPU run-length encode, host glue/merge, CSV",
                        "frames_per_gpu_timed": frames_done, "segments_out": int(len(merged["start_frames"])),
                        "stitch": "all-gather of (class,max) streams over RCCL" if world > 1 else "none"},
             "roofline": {
                 "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
                 "traffic": traffic, "traffic_unit": "bytes per 256-frame launch (rocprofv3 PMC, profiles/)",
                 "launch_ms": round(conv2_ms, 4), "flops_per_frame": FLOPS_CONV2,
                 "frames_per_launch": round(frames_per_launch, 2),
                 "whole_net_tflops": round(FLOPS_FRAME * fps / world / 1e12, 2),
-                "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "hbm_compulsory_GBps": round(BYTES_FRAME_720P * fps / world / 1e9, 2),
-                "hbm_frac_of_peak": round(BYTES_FRAME_720P * fps / world / 1e9 / PEAK_HBM_GBS, 5),
+                "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps / world / 1e12 / peak_tflops, 4),
+                "hbm_compulsory_GBps": round(bytes_frame * fps / world / 1e9, 2),
+                "hbm_frac_of_peak": round(bytes_frame * fps / world / 1e9 / PEAK_HBM_GBS, 5),
             },
             "stages": stages,
         }
