@@ -23,9 +23,10 @@ class ProdNet:
 
     training = False
 
-    def __init__(self, blob, params):
+    def __init__(self, blob, params, dtype="f32"):
         self._blob = blob
         self.params = dict(params)
+        self.dtype = dtype            # "f32" (the reference's arithmetic) or "bf16" (see cutdet.Engine)
         self._device = torch.device("cpu")
         self._engine = None
 
@@ -44,7 +45,7 @@ class ProdNet:
             idx = device.index if device.index is not None else torch.cuda.current_device()
             device = torch.device("cuda", idx)
             if self._engine is None or self._engine.device != device:
-                self._engine = Engine(self._blob, device)
+                self._engine = Engine(self._blob, device, self.dtype)
         self._device = device
         return self
 
@@ -71,16 +72,17 @@ class ProdNet:
 
 
 # Function to slightly simplify loading networks and making a single callable.
-def load_and_glue_nets(param_file, conv_file, linear_file):
+def load_and_glue_nets(param_file, conv_file, linear_file, dtype="f32"):
     """Build the classifier from the reference's three files (JSON hyper-parameters and the
     two state-dict `.pt` files); returns `(net, model_params)`."""
     blob, model_params = weights.pack_reference_files(param_file, conv_file, linear_file)
-    return ProdNet(blob, model_params), model_params
+    return ProdNet(blob, model_params, dtype), model_params
 
 
 # Load a specific network that's included in the module.
-def load_default_net():
-    """The bundled production classifier (the same weights as the reference's prod_net)."""
+def load_default_net(dtype="f32"):
+    """The bundled production classifier (the same weights as the reference's prod_net).  `dtype` is
+    an addition to the reference's signature: "bf16" selects the bf16 matrix-core arithmetic."""
     with open(api.DEFAULT_MANIFEST, "r") as f:
         model_params = json.load(f)["model_params"]
-    return ProdNet(api.default_blob(), model_params), model_params
+    return ProdNet(api.default_blob(), model_params, dtype), model_params

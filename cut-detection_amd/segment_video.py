@@ -49,6 +49,8 @@ def build_parser():
         p.add_argument(flag, type=typ, default=default, help=text)
     p.add_argument("--cpu", action="store_true", help="Not available in this build (GPU only).")
     p.add_argument("--device", type=str, default="cuda:0", help="GPU to run on.")
+    p.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                   help="Arithmetic of the classifier: f32 (the reference's) or bf16 matrix cores.")
     return p
 
 
@@ -66,7 +68,7 @@ def main(args):
     logging.info(f"Using {device}")
 
     ds = VideoDataset(args.input_path, resize=256, device=device)
-    net, params = load_default_net()
+    net, params = load_default_net(getattr(args, "dtype", "f32"))
     net.eval()
     net.to(device)
     logging.info("Loaded default classifier.")

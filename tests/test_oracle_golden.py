@@ -72,6 +72,17 @@ def test_traced_equals_eager(weights):
     assert (t(x) - onet.forward(weights, x)).abs().max().item() == 0.0
 
 
+def test_bf16_restatement_stays_near_the_pinned_fp32_net(weights):
+    """forward_bf16 (what the GPU's bf16 mode is checked against) rounds inputs, weights and the first
+    two activations to bfloat16; it must stay within a few 1e-2 of the pinned fp32 forward and keep
+    the class of every synthetic generator."""
+    frames = np.stack([synth.frame(SEED, i, i % 3, 720, 1280) for i in range(6)])
+    x = preprocess.preprocess_batch(frames)
+    y32, y16 = onet.forward(weights, x), onet.forward_bf16(weights, x)
+    assert 1e-4 < float((y32 - y16).abs().max()) <= 8e-2
+    assert y16.argmax(1).tolist() == y32.argmax(1).tolist() == [0, 1, 2, 0, 1, 2]
+
+
 # ----------------------------------------------------------------------------- segmentation
 def _load_seg(golden_dir):
     with open(os.path.join(golden_dir, "seg_golden.json")) as f:
