@@ -172,11 +172,7 @@ __device__ __forceinline__ uint32_t point_fetch_piece(const uint8_t* __restrict_
     const uint8_t* p = fsrc + (int64_t)(sa.affine ? sa.ym * gyc + sa.ya : sa.sy[gyc]) * sa.row_stride +
                        (u < kC1Rows ? c.a : c.a2);
     const bool ok = gy >= 0 && gy < H && (u < kC1Rows ? c.xin : tid < kC1Rows);
-#ifdef CD_ABL_STAGE
-    return (ok && p == nullptr) ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
-#else
     return ok ? *reinterpret_cast<const u32_unaligned*>(p) : 0u;
-#endif
 }
 
 __device__ __forceinline__ void put_pixel(float* tile, int r, int c, uint32_t px, bool bgr) {
@@ -444,13 +440,6 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
                     const int s = row / 3, t = row % 3;
                     const int cur = (nt * 21 + row) & 1;
                     const int nrow = row < 20 ? row + 1 : 0, ns = nrow / 3, ntt = nrow % 3;
-#ifdef CD_C1_NOPIPE
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) a[cur][j] = tile[addr[s][j] + t * kC1RS];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[t][j] = mfma4(a[cur][j], bw[s][nt], s == 0 ? bias4 : acc[t][j]);
-                    (void)ns; (void)ntt;
-#else
                     if (row < 20 || nt < 2) {
 #pragma unroll
                         for (int j = 0; j < 3; ++j) a[cur ^ 1][j] = tile[addr[ns][j] + ntt * kC1RS];
@@ -459,7 +448,6 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc[t][j] = mfma4(a[cur][j], bw[s][nt], s == 0 ? bias4 : acc[t][j]);
                     __builtin_amdgcn_sched_barrier(0);
-#endif
                 }
                 const float sc = spost[kC + nt * 16 + ch], sh = spost[2 * kC + nt * 16 + ch];
                 // epilogue: lane (q, ch) owns pool windows 4q .. 4q+3 of the tile for channel ch + 16 nt.
