@@ -103,3 +103,29 @@ def test_create_rejects_unknown_dtype():
     with pytest.raises(ValueError):
         from cutdet.engine import Engine
         Engine(blob, "cuda:0", dtype="fp8")
+
+
+def test_random_views_both_modes(engines, oracle_weights):
+    """Batch sizes that do not fill the 8-way workgroup interleave, padded row strides, cropped
+    views with an offset start, either channel order, assorted geometries: resized floats exact,
+    fp32 logits within 1e-3 of the oracle, bf16 logits within the bf16 bars."""
+    from cutdet import _lib
+    from oracle import net as onet, preprocess as opre
+    e32, e16 = engines
+    rng = np.random.default_rng(11)
+    geoms = [(720, 1280), (1080, 1920), (180, 320), (360, 640), (100, 300), (430, 512)]
+    for trial in range(12):
+        H0, W0 = geoms[trial % len(geoms)]
+        n = int(rng.choice([1, 2, 3, 5, 7, 9, 17]))
+        pad = int(rng.choice([0, 3, 16, 37]))
+        order = trial & 1
+        full = torch.from_numpy(rng.integers(0, 256, size=(n, H0 + 2, W0 + pad, 3), dtype=np.uint8)).to(e32.device)
+        frames = full[:, 1:H0 + 1, :W0, :]
+        x_ref = opre.preprocess_batch(frames.cpu().numpy(), chan_order=order)
+        assert np.array_equal(e32.preprocess(frames, chan_order=order).cpu().numpy(), x_ref)
+        ref32, ref16 = onet.forward(oracle_weights, x_ref), onet.forward_bf16(oracle_weights, x_ref)
+        l32 = e32.forward_u8(frames, chan_order=order)[0].cpu()
+        l16 = e16.forward_u8(frames, chan_order=order)[0].cpu()
+        assert float((l32 - ref32).abs().max()) <= 1e-3, (trial, H0, W0, n, pad, order)
+        assert float((l16 - ref16).abs().max()) <= TOL_SAME_ARITHMETIC, (trial, H0, W0, n, pad, order)
+        assert float((l16 - ref32).abs().max()) <= 0.25      # random noise frames: larger activations than the clips
