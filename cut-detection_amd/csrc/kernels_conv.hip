@@ -665,25 +665,26 @@ __device__ __forceinline__ void conv48_load_step(const typename Prec<BF>::elem* 
             a[t][j] = *reinterpret_cast<const frag*>(patch + base[j] + off + t * PITCH * kC);
 }
 
-template <int PITCH, bool BF>
+// Steps S0 .. S1-1 of the 27 (a K range: the accumulators then hold a partial sum).
+template <int PITCH, bool BF, int S0 = 0, int S1 = 27>
 __device__ __forceinline__ void conv48_wave_tile(const typename Prec<BF>::elem* patch, const int (&base)[3],
                                                  __amdgpu_buffer_rsrc_t wr, int lane, f32x4 (&acc)[3][3][3]) {
     typedef typename Prec<BF>::frag frag;
     constexpr int kM = 27 * Prec<BF>::kSub;      // MFMAs per step
     frag a[2][3][3], b[2][3];
-    conv48_load_step<PITCH, BF>(patch, base, wr, lane, 0, a[0], b[0]);
+    conv48_load_step<PITCH, BF>(patch, base, wr, lane, S0, a[S0 & 1], b[S0 & 1]);
 #pragma unroll
-    for (int s = 0; s < 27; ++s) {
+    for (int s = S0; s < S1; ++s) {
         const int cur = s & 1;
         const int nk = (s + 1) / 3, ng = (s + 1) % 3;
         const int off = ((nk / 3) * PITCH + (nk % 3)) * kC + 16 * ng;
         // next step's 3 weight loads and 9 LDS reads go out one per MFMA: with one wave per SIMD,
         // anything issued as a block between two MFMAs leaves the matrix pipe idle
-        const int n_side = s + 1 < 27 ? 12 : 0;
+        const int n_side = s + 1 < S1 ? 12 : 0;
 #pragma unroll
         for (int m = 0; m < kM; ++m) {
             const int e = m / 27, t = (m / 9) % 3, j = (m / 3) % 3, nt = m % 3;
-            if (s == 0 && e == 0)
+            if (s == S0 && e == 0)
                 acc[t][j][nt] = mfma_frag<BF>(a[cur][t][j], b[cur][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
             else
                 acc[t][j][nt] = mfma_frag<BF>(a[cur][t][j], b[cur][nt], e, acc[t][j][nt]);
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     const typename Prec<BF>::elem* __restrict__ in, const void* __restrict__ wfrag, const float* __restrict__ post,
     const float* __restrict__ fc0w, const float* __restrict__ fc0p, const float* __restrict__ fc1w,
     const float* __restrict__ fc1b, float* __restrict__ logits, float* __restrict__ maxv,
-    int64_t* __restrict__ argmax, int Hin, int Hp) {
+    int64_t* __restrict__ argmax, int Hin, int Hp, int spare_off) {
     typedef typename Prec<BF>::elem elem;
     constexpr int kEs = Prec<BF>::kEs;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1055,19 +1056,19 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CD_STAMP3();
-    // Everything else that does not depend on the activations is requested now and lands while the
-    // convolution runs: a dependent global load costs more than a microsecond here, and the head
-    // would otherwise pay that once per layer.  A thread's 96 weights of Linear(768,32) (8 threads
-    // per output) stay in registers through the convolution.
+    // The small parameters that do not depend on the activations are requested now and land while
+    // the convolution runs: a dependent global load costs more than a microsecond here, and the head
+    // would otherwise pay that once per layer.
     const int fo = tid >> 3, part = tid & 7;
     f32x4 w0[24];
-    {
-        // 16-byte piece k*8 + part of the output's weight row: the 8 threads of an output read 128
-        // contiguous bytes per load
+    // 16-byte piece k*8 + part of the output's weight row: the 8 threads of an output read 128
+    // contiguous bytes per load.  Requested when the convolution is over (its accumulators need the
+    // registers) and used three barriers later.
+    auto load_fc0 = [&]() {
         const f32x4* wrow = reinterpret_cast<const f32x4*>(fc0w + fo * kFeat) + part;
 #pragma unroll
         for (int k = 0; k < 24; ++k) w0[k] = wrow[k * 8];
-    }
+    };
     const float h_bias = fc0p[fo], h_scale = fc0p[kHid + fo], h_shift = fc0p[2 * kHid + fo];
     float pbias[3], pscale[3], pshift[3];
 #pragma unroll
@@ -1079,21 +1080,21 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
 
     const int windows = Hp * kW3;
     const int wave_tiles = (windows + 15) / 16;
-    for (int wt = wave; wt < wave_tiles; wt += 4) {
-        const int w0i = wt * 16;
-        int base[3];
+    const __amdgpu_buffer_rsrc_t wr = weight_rsrc<BF>(wfrag);
+    // LDS offsets of the pixels that A-row i of column group j maps to in wave tile wt.  Columns of
+    // one lane's 12 may straddle pool rows here, so tile (t, j) of lane-row i uses base[j] for every
+    // t and the conv row offset t is applied inside the tile routine.
+    auto tile_base = [&](int wt, int (&base)[3]) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             int c12 = 4 * j + (i & 3);
-            int W = min(w0i + 4 * (i >> 2) + c12 / 3, windows - 1);
+            int W = min(wt * 16 + 4 * (i >> 2) + c12 / 3, windows - 1);
             int wrow = W / kW3, px = W % kW3;
             base[j] = ((3 * wrow) * kP3W + 3 * px + c12 % 3) * kC + 4 * kq;
         }
-        f32x4 acc[3][3][3];
-        // columns of one lane's 12 may straddle pool rows here, so tile (t, j) of lane-row i uses
-        // base[j] for every t and the conv row offset t is applied inside the tile routine
-        conv48_wave_tile<kP3W, BF>(patch, base, weight_rsrc<BF>(wfrag), lane, acc);
-        CD_STAMP3();
+    };
+    // ReLU + 3x3 max + bias + BatchNorm affine of one wave tile -> pooled[]
+    auto tile_epilogue = [&](int wt, const f32x4 (&acc)[3][3][3]) {
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int c = nt * 16 + ch;
@@ -1101,12 +1102,68 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
                           window_max<3>(acc, nt)};
 #pragma unroll
             for (int wi = 0; wi < 4; ++wi) {
-                int W = w0i + 4 * q + wi;
+                int W = wt * 16 + 4 * q + wi;
                 if (W < windows) pooled[W * kC + c] = fmaf(fmaxf(m[wi] + pbias[nt], 0.f), pscale[nt], pshift[nt]);
             }
         }
+    };
+    // Up to three wave tiles (45 windows at 144 input rows) would leave the fourth wave, a quarter of
+    // the CU's matrix throughput, idle.  Then (the host passes spare_off >= 0) the K range is split
+    // instead: waves 0-2 run steps 0..19 of their tile, wave 3 runs steps 20..26 of all of them (21
+    // steps) and hands its partial sums over through LDS.
+    constexpr int kSplit = 20;
+    if (spare_off >= 0) {
+        if constexpr (!BF) {
+            // wave 3 keeps at most two tiles' partial sums in registers: the first tile's go to a
+            // spare LDS buffer behind the head's arrays as soon as they are complete
+            f32x4* spare = reinterpret_cast<f32x4*>(smem + spare_off);   // [27 accumulators][64 lanes]
+            f32x4* parts = reinterpret_cast<f32x4*>(patch);              // same, per tile, once the patch is dead
+            f32x4 acc[3][3][3], extra[3][3][3];
+            int base[3];
+            if (wave < 3) {
+                if (wave < wave_tiles) {
+                    tile_base(wave, base);
+                    conv48_wave_tile<kP3W, BF, 0, kSplit>(patch, base, wr, lane, acc);
+                }
+            } else {
+                tile_base(0, base);
+                conv48_wave_tile<kP3W, BF, kSplit, 27>(patch, base, wr, lane, acc);
+#pragma unroll
+                for (int k = 0; k < 27; ++k) spare[k * 64 + lane] = acc[k / 9][(k / 3) % 3][k % 3];
+                if (wave_tiles > 1) { tile_base(1, base); conv48_wave_tile<kP3W, BF, kSplit, 27>(patch, base, wr, lane, acc); }
+                if (wave_tiles > 2) { tile_base(2, base); conv48_wave_tile<kP3W, BF, kSplit, 27>(patch, base, wr, lane, extra); }
+            }
+            CD_STAMP3();
+            __syncthreads();                                   // every wave is done reading the patch
+            if (wave == 3) {
+#pragma unroll
+                for (int k = 0; k < 27; ++k) {
+                    if (wave_tiles > 1) parts[(27 + k) * 64 + lane] = acc[k / 9][(k / 3) % 3][k % 3];
+                    if (wave_tiles > 2) parts[(54 + k) * 64 + lane] = extra[k / 9][(k / 3) % 3][k % 3];
+                }
+            }
+            __syncthreads();
+            load_fc0();
+            if (wave < 3 && wave < wave_tiles) {
+                const f32x4* mine = wave == 0 ? spare : parts + wave * 27 * 64;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) acc[k / 9][(k / 3) % 3][k % 3] += mine[k * 64 + lane];
+                tile_epilogue(wave, acc);
+            }
+            CD_STAMP3();
+        }
+    } else {
+        for (int wt = wave; wt < wave_tiles; wt += 4) {
+            int base[3];
+            tile_base(wt, base);
+            f32x4 acc[3][3][3];
+            conv48_wave_tile<kP3W, BF>(patch, base, wr, lane, acc);
+            tile_epilogue(wt, acc);
+        }
+        load_fc0();
+        CD_STAMP3();
+        CD_STAMP3();
     }
-    if (wave == 3) CD_STAMP3();
     CD_STAMP3();
     __syncthreads();
     CD_STAMP3();
@@ -1176,19 +1233,28 @@ int init_conv3_head() {
 int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logits, float* maxv,
                       int64_t* argmax, hipStream_t s) {
     const bool bf = h->dtype == CD_BF16;
-    const size_t lds = head_lds_bytes(g, bf ? 2 : 4);
+    size_t lds = head_lds_bytes(g, bf ? 2 : 4);
     if (lds > (size_t)kLdsBytes) {
         set_error("network input of %d rows needs %zu bytes of LDS in the head kernel (max %d)", g.h, lds, kLdsBytes);
         return CD_EINVAL;
     }
+    // K split over the fourth wave (fp32, at most three wave tiles): needs one tile's accumulators
+    // (27 x 64 x 16 bytes) of spare LDS, and room for the others in the patch once it is dead
+    const int wave_tiles = (g.h3 * kW3 + 15) / 16;
+    const size_t part = (size_t)27 * 64 * 16, patch_bytes = (size_t)(g.h2 + 2) * (kW2 + 2) * kC * 4;
+    int spare_off = -1;
+    if (!bf && wave_tiles <= 3 && wave_tiles * part <= patch_bytes && lds + part <= (size_t)kLdsBytes) {
+        spare_off = (int)((lds + 15) / 16 * 4);            // floats, 16-byte aligned
+        lds = (size_t)spare_off * 4 + part;
+    }
     if (bf)
         hipLaunchKernelGGL(conv3_head_kernel<true>, dim3((unsigned)n), dim3(256), lds, s,
                            reinterpret_cast<const uint16_t*>(h->act2), (const void*)h->p.w3b, h->p.post + 6 * kC,
-                           h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3);
+                           h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3, spare_off);
     else
         hipLaunchKernelGGL(conv3_head_kernel<false>, dim3((unsigned)n), dim3(256), lds, s, (const float*)h->act2,
                            (const void*)h->p.w3, h->p.post + 6 * kC, h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b,
-                           logits, maxv, argmax, g.h2, g.h3);
+                           logits, maxv, argmax, g.h2, g.h3, spare_off);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
