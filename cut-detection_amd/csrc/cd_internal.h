@@ -51,9 +51,10 @@ struct Geometry {               // per network-input height
     int h, h1, h2, h3;          // input rows, rows after each conv block
 };
 inline Geometry geometry(int h) { Geometry g; g.h = h; g.h1 = h / 3; g.h2 = g.h1 / 3; g.h3 = g.h2 / 3; return g; }
-// LDS of the block-3 + head kernel: padded block-2 frame, pooled block-3 tensor, features, hidden units
+// LDS of the block-3 + head kernel: padded block-2 frame, pooled block-3 tensor, features, hidden units,
+// block-3 bias / BatchNorm terms
 inline size_t head_lds_bytes(const Geometry& g, int elem_bytes) {
-    return (size_t)elem_bytes * (g.h2 + 2) * (kW2 + 2) * kC + sizeof(float) * ((size_t)g.h3 * kW3 * kC + kFeat + kHid);
+    return (size_t)elem_bytes * (g.h2 + 2) * (kW2 + 2) * kC + sizeof(float) * ((size_t)g.h3 * kW3 * kC + kFeat + kHid + 3 * kC);
 }
 
 // ---- resize tables (device) -------------------------------------------------------------------

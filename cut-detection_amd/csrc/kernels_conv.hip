@@ -77,10 +77,12 @@ __device__ __forceinline__ f32x4 mfma_frag(const typename Prec<BF>::frag& a, con
     else return mfma4(a[e], b[e], c);
 }
 // two fp32 values -> two bf16 (round to nearest even) in one dword, `lo` in the low half
+// (compiles to v_cvt_pk_bf16_f32; written as a conversion, not inline asm, so that the compiler
+// keeps its own hazard bookkeeping around it)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // Pool-window max of one lane: columns 3*wi .. 3*wi+2 of its 12 columns, rows t = 0..2.
@@ -95,15 +97,21 @@ __device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3][3], int nt)
     return m;
 }
 
-// 3x3 max of pool window WI over single-group accumulators, seeded with 0: ReLU folded in.
+// ReLU of the 3x3 max of pool window WI over single-group accumulators, as a signed-integer max of
+// the bit patterns with 0: every negative float is a negative integer, non-negative floats order
+// like their bit patterns, so max(0, bits...) is exactly relu(max(...)).  Integer maxima fuse into
+// v_max3_i32 (4 + 1 instructions per window); the float form costs the compiler an extra
+// NaN-quieting instruction per operand, and each of these is a VALU slot the MFMAs cannot use.
+// (Inline-asm v_max3_f32 is not an option: the compiler does not guard inline asm against the
+// MFMA-result read hazard.)
 template <int WI>
 __device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3]) {
-    float m = 0.f;
+    int m = 0;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int c = 3 * WI; c < 3 * WI + 3; ++c) m = fmaxf(m, acc[t][c >> 2][c & 3]);
-    return m;
+        for (int c = 3 * WI; c < 3 * WI + 3; ++c) m = max(m, __float_as_int(acc[t][c >> 2][c & 3]));
+    return __int_as_float(m);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -131,12 +139,12 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 #endif
 constexpr int kC1MaxChunksPerWG = CD_C1_CPW;   // consecutive 3-pool-row chunks one workgroup walks
 
-// Correctly rounded k / 255 for k = 0..255 without a table: one Newton correction of k * (1/255)
-// (checked exhaustively against the division data.py:227 performs).
+// Correctly rounded k / 255 for k = 0..255 without a table: 1/255 as a two-term constant, the fma
+// rounds k * (hi + lo) once (checked exhaustively, in exact arithmetic, against the division
+// data.py:227 performs).
 __device__ __forceinline__ float byte_to_unit(float k) {
-    const float r = 1.0f / 255.0f;
-    const float q = k * r;
-    return fmaf(fmaf(-255.0f, q, k), r, q);
+    const float hi = 0x1.010102p-8f, lo = -0x1.fdfdfep-33f;     // hi = fl(1/255), lo = fl(1/255 - hi)
+    return fmaf(k, hi, k * lo);
 }
 
 // Staging helpers -------------------------------------------------------------------------
@@ -1029,6 +1037,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     float* pooled = smem + (Hin + 2) * kP3W * kC * kEs / 4;   // [Hp][9][48]
     float* feat = pooled + Hp * kW3 * kC;                 // [768]
     float* hid = feat + kFeat;                            // [32]
+    float* spost = hid + kHid;                            // [3][48] bias, BN scale, BN shift of block 3
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -1070,11 +1079,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
         for (int k = 0; k < 24; ++k) w0[k] = wrow[k * 8];
     };
     const float h_bias = fc0p[fo], h_scale = fc0p[kHid + fo], h_shift = fc0p[2 * kHid + fo];
-    float pbias[3], pscale[3], pshift[3];
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-        pbias[nt] = post[nt * 16 + ch]; pscale[nt] = post[kC + nt * 16 + ch]; pshift[nt] = post[2 * kC + nt * 16 + ch];
-    }
+    if (tid < 3 * kC) spost[tid] = post[tid];     // visible to the epilogues after the barriers that follow
     const float l_w01 = fc1w[min(tid >> 5, 1) * kHid + (tid & 31)], l_w2 = fc1w[2 * kHid + (tid & 31)];
     const float l_b0 = fc1b[0], l_b1 = fc1b[1], l_b2 = fc1b[2];
 
@@ -1098,12 +1103,13 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int c = nt * 16 + ch;
+            const float bias = spost[c], sc = spost[kC + c], sh = spost[2 * kC + c];
             float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
                           window_max<3>(acc, nt)};
 #pragma unroll
             for (int wi = 0; wi < 4; ++wi) {
                 int W = wt * 16 + 4 * q + wi;
-                if (W < windows) pooled[W * kC + c] = fmaf(fmaxf(m[wi] + pbias[nt], 0.f), pscale[nt], pshift[nt]);
+                if (W < windows) pooled[W * kC + c] = fmaf(fmaxf(m[wi] + bias, 0.f), sc, sh);
             }
         }
     };
