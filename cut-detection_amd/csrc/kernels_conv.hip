@@ -739,21 +739,6 @@ template <bool BF> struct G2 {
 
 template <bool BF> struct Conv2Tile { const char* src; typename Prec<BF>::elem* dst; int ty, tx; };
 
-template <bool BF>
-__device__ __forceinline__ void conv2_load_step(const typename Prec<BF>::elem* buf, const int (&base)[3],
-                                                __amdgpu_buffer_rsrc_t wr, int lane, int g, int kk,
-                                                typename Prec<BF>::frag (&a)[3][3], typename Prec<BF>::frag (&b)[3]) {
-    typedef typename Prec<BF>::frag frag;
-    const int off = ((kk / 3) * kP2 + (kk % 3)) * 16;
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt) b[nt] = load_frag<BF>(wr, lane, (kk * 3 + g) * 3 + nt);
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            a[t][j] = *reinterpret_cast<const frag*>(buf + base[j] + off + t * kP2 * 16);
-}
-
 // LDS-DMA of one channel group of a patch: wave-wide 16-byte copies, LDS image linear.
 // All 64 lanes take part in the last copy as well (no exec-masked region: a branch here makes the
 // compiler shuttle all 108 accumulators between AGPRs and VGPRs once per unit): its surplus
@@ -939,14 +924,21 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     Conv2Tile<BF> cur = locate(id);
     int next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
     Conv2Tile<BF> nxt = locate(next_id);
+    // everything the first step needs from global memory is requested together: the patch copy,
+    // step 0's weight fragments and the affine terms share one round trip
+    frag a[2][3][3], b[2][3];
+    f32x4 acc[3][3][3];
     conv2_dma_group<BF>(cur.src, bufs, rel, lane);
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) b[0][nt] = load_frag<BF>(wr, lane, nt);
     spost[lane] = post[lane];
     spost[64 + lane] = post[64 + lane];
     if (lane < 3 * kC - 128) spost[128 + lane] = post[128 + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    frag a[2][3][3], b[2][3];
-    f32x4 acc[3][3][3];
-    conv2_load_step<BF>(bufs, base, wr, lane, 0, 0, a[0], b[0]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[0][t][j] = *reinterpret_cast<const frag*>(bufs + base[j] + t * kP2 * 16);
     CD_STAMP();
 
     // One loop iteration = one wave tile = three units.  `first` is the buffer (as an element
