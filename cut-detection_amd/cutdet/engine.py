@@ -18,6 +18,18 @@ def output_size(height, width, resize=NET_W):
     return int(height * (resize / width)), resize
 
 
+def sampled_source_rows(height, width, resize=NET_W):
+    """Source rows the resize reads when its vertical pass is a pure point sample (the source height
+    an odd integer multiple of the output height, e.g. 720 -> 144 reads rows 5y+2), else None.
+    Uploading only these rows - 1/5 of a 720p frame - and classifying them with
+    forward_u8(..., net_h=len(rows)) gives bit-identical results: the vertical scale is then 1."""
+    nh, _ = output_size(height, width, resize)
+    if nh < 1 or height % nh or (height // nh) % 2 == 0:
+        return None
+    s = height // nh
+    return [s * y + (s - 1) // 2 for y in range(nh)]
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -112,11 +124,15 @@ class Engine:
             check(lib.cd_forward(self._h, _ptr(x), n, nh, nw, _ptr(logits), _ptr(mx), _ptr(am), self._stream()))
         return (logits, mx, am) if want_max else logits
 
-    def forward_u8(self, frames, chan_order=_lib.CD_BGR, resize=NET_W, want_max=True, out=None):
+    def forward_u8(self, frames, chan_order=_lib.CD_BGR, resize=NET_W, want_max=True, out=None, net_h=None):
         """u8 [n,H0,W0,3] -> logits (and max, argmax) with the resize fused into the first layer.
-        `out` = (logits, max, argmax) tensors to write into (e.g. slices of clip-long buffers)."""
+        `out` = (logits, max, argmax) tensors to write into (e.g. slices of clip-long buffers).
+        `net_h` overrides the output height the reference's size rule would give; it is for frames
+        that were already reduced to their sampled rows (see sampled_source_rows)."""
         n, H0, W0, rs, fs = self._frame_layout(frames)
         nh, nw = output_size(H0, W0, resize)
+        if net_h is not None:
+            nh = int(net_h)
         logits, mx, am = self._outputs(n, want_max, out)
         check(lib.cd_forward_u8(self._h, _ptr(frames), n, H0, W0, rs, fs, chan_order, nh, nw, _ptr(logits),
                                 _ptr(mx), _ptr(am), self._stream()))

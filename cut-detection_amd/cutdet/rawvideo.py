@@ -67,11 +67,14 @@ class RawVideoCapture:
         self._pos += 1
         return True, frame
 
-    def read_batch(self, n):
-        """Up to n consecutive frames as one [k, H, W, 3] array (k = 0 at the end)."""
+    def read_batch(self, n, rows=None):
+        """Up to n consecutive frames as one [k, H, W, 3] array (k = 0 at the end); with `rows`, only
+        those rows of each frame ([k, len(rows), W, 3]) - the other rows are never read from the file."""
         a, b = self._pos, min(self.length, self._pos + n)
         self._pos = b
-        return np.array(self._frames[a:b])
+        if rows is None:
+            return np.array(self._frames[a:b])
+        return np.ascontiguousarray(self._frames[a:b][:, np.asarray(rows, dtype=np.int64)])
 
     def release(self):
         self._frames = None

@@ -13,6 +13,7 @@ import torch
 from torch.utils.data import IterableDataset
 
 from cutdet import api, rawvideo
+from cutdet.engine import sampled_source_rows
 
 
 class SupervisedFrameDataset:
@@ -59,12 +60,21 @@ class VideoDataset(IterableDataset):
             self.new_height = None
         self._ready = None   # preprocessed frames of the current read-ahead batch
         self._next = 0
+        # Rows the resize actually reads, when the container can hand over rows and the vertical pass
+        # is a point sample (720p: 144 of 720 rows): frame_batches() then uploads only those, which
+        # is what bounds real clips (2.76 MB per 720p frame over PCIe), and `batch_net_height` tells
+        # the classifier that the rows are already the network's.
+        self.sampled_rows = None
+        if resize is not None and hasattr(self.cap, "read_batch"):
+            self.sampled_rows = sampled_source_rows(self.video_info["height"], self.video_info["width"], resize)
+        self.batch_net_height = self.new_height if self.sampled_rows is not None else None
 
     # --- decoded frames ------------------------------------------------------------------
-    def read_u8_batch(self, n):
-        """Next up-to-n decoded frames as a u8 [k,H,W,3] tensor on the GPU (k = 0 at the end)."""
+    def read_u8_batch(self, n, rows=None):
+        """Next up-to-n decoded frames as a u8 [k,H,W,3] tensor on the GPU (k = 0 at the end);
+        `rows` (raw container only) restricts every frame to those rows."""
         if hasattr(self.cap, "read_batch"):
-            arr = self.cap.read_batch(n)
+            arr = self.cap.read_batch(n, rows) if rows is not None else self.cap.read_batch(n)
             host = torch.from_numpy(arr)
         else:
             got = []
@@ -77,10 +87,15 @@ class VideoDataset(IterableDataset):
                                                              self.video_info["width"], 3), dtype=torch.uint8)
         return host.to(self.device, non_blocking=False)
 
-    def frame_batches(self, batch_size):
-        """Yields u8 GPU batches for the fused classify path (no float frames materialised)."""
+    def frame_batches(self, batch_size, sampled=True):
+        """Yields u8 GPU batches for the fused classify path (no float frames materialised).  With
+        `sampled` and a point-sampling geometry the batches hold only the sampled rows
+        ([k, new_height, W, 3]); classify them with net_h=self.batch_net_height."""
+        rows = self.sampled_rows if sampled else None
+        if rows is None:
+            self.batch_net_height = None
         while True:
-            b = self.read_u8_batch(batch_size)
+            b = self.read_u8_batch(batch_size, rows)
             if b.shape[0] == 0:
                 return
             yield b

@@ -66,9 +66,10 @@ class ProdNet:
 
     forward = __call__
 
-    def classify_frames(self, frames_u8, chan_order=0):
-        """Decoded u8 frames [B,H0,W0,3] on the GPU -> (logits, max, argmax); resize fused in."""
-        return self.engine.forward_u8(frames_u8, chan_order=chan_order)
+    def classify_frames(self, frames_u8, chan_order=0, net_h=None):
+        """Decoded u8 frames [B,H0,W0,3] on the GPU -> (logits, max, argmax); resize fused in.
+        `net_h`: see cutdet.Engine.forward_u8 (frames already reduced to their sampled rows)."""
+        return self.engine.forward_u8(frames_u8, chan_order=chan_order, net_h=net_h)
 
 
 # Function to slightly simplify loading networks and making a single callable.

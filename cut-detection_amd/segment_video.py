@@ -75,7 +75,7 @@ def main(args):
 
     scores, classes, best = [], [], []
     for i, frames in enumerate(ds.frame_batches(args.batch_size)):
-        logits, mx, am = net.classify_frames(frames, chan_order=ds.chan_order)
+        logits, mx, am = net.classify_frames(frames, chan_order=ds.chan_order, net_h=ds.batch_net_height)
         scores.append(logits)
         best.append(mx)
         classes.append(am)

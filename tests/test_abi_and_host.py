@@ -157,7 +157,18 @@ def test_raw_video_container(tmp_path):
     assert ok and (f0 == frames[0]).all()
     assert (cap.read_batch(10) == frames[1:]).all()
     assert cap.read() == (False, None)
+    cap2, _ = data.open_video(p)
+    assert (cap2.read_batch(3, rows=[1, 4]) == frames[:3][:, [1, 4]]).all()      # row-restricted ingest
     assert data.SupervisedFrameDataset.lab_enum == {"a22": 0, "ez": 1, "b": 2}
+
+
+def test_sampled_source_rows():
+    from cutdet.engine import sampled_source_rows
+    assert sampled_source_rows(720, 1280) == [5 * y + 2 for y in range(144)]     # data.py:199-202, cv2 point sample
+    assert sampled_source_rows(144, 256) == list(range(144))                      # scale 1
+    assert sampled_source_rows(1080, 1920) is None                                # scale 7.5: two rows per output row
+    assert sampled_source_rows(180, 320) is None                                  # scale 1.25
+    assert sampled_source_rows(288, 512) is None                                  # scale 2: box average
 
 
 def test_cli_parser_matches_reference_defaults():

@@ -263,6 +263,31 @@ def test_segment_video_cli_1k_frames_320x180(engine, oracle_weights, tmp_path):
         mod.main(mod.sv_parser.parse_args([path, "--cpu"]))
 
 
+def test_sampled_row_ingest_is_bit_identical(engine, tmp_path):
+    """720p clip from the raw container: uploading only the 144 sampled rows of each frame and
+    classifying them with net_h=144 must give the same logits, bit for bit, as the full frames."""
+    from frameID.data import VideoDataset
+    from frameID.net import load_default_net
+    runs = [(0, 20), (1, 25), (2, 19)]
+    path, frames, cl = _write_clip(tmp_path, runs, 720, 1280)
+    net, _ = load_default_net()
+    net.eval().to(engine.device)
+    full = VideoDataset(path, resize=256, device=engine.device)
+    a = torch.cat([net.classify_frames(b, chan_order=full.chan_order)[0] for b in full.frame_batches(32, sampled=False)])
+    ds = VideoDataset(path, resize=256, device=engine.device)
+    assert ds.sampled_rows == [5 * y + 2 for y in range(144)]
+    got = []
+    for b in ds.frame_batches(32):
+        assert tuple(b.shape[1:]) == (144, 1280, 3) and ds.batch_net_height == 144
+        got.append(net.classify_frames(b, chan_order=ds.chan_order, net_h=ds.batch_net_height))
+    assert torch.equal(a, torch.cat([g[0] for g in got]))
+    assert torch.cat([g[2] for g in got]).cpu().tolist() == cl
+    # a geometry that is not a point sample keeps whole frames
+    p2, _, _ = _write_clip(tmp_path, [(0, 3)], 180, 320)
+    d2 = VideoDataset(p2, resize=256, device=engine.device)
+    assert d2.sampled_rows is None and next(iter(d2.frame_batches(8))).shape[1] == 180 and d2.batch_net_height is None
+
+
 def test_reference_style_driver_loop(engine, oracle_weights, tmp_path):
     """The reference's loop verbatim in shape: VideoDataset -> DataLoader -> net(batch) -> Segmentation."""
     from torch.utils.data import DataLoader
