@@ -9,9 +9,9 @@ from oracle import net as onet, preprocess as opre
 e32 = api.default_engine("cuda:0"); e16 = api.default_engine("cuda:0", "bf16")
 w = onet.load_blob()
 rng = np.random.default_rng(7)
-geoms = [(720, 1280), (1080, 1920), (180, 320), (480, 640), (360, 640), (100, 300), (27 * 4, 256 * 4), (430, 512), (300, 400)]
+geoms = [(720, 1280), (1080, 1920), (180, 320), (480, 640), (360, 640), (100, 300), (27 * 4, 256 * 4), (430, 512), (300, 400), (36, 64), (27, 48), (90, 160), (144, 256), (9, 16), (2160, 3840), (54, 96), (600, 800)]
 worst32 = worst16 = 0.0
-for trial in range(40):
+for trial in range(68):
     H0, W0 = geoms[trial % len(geoms)]
     n = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 17, 31]))
     pad = int(rng.choice([0, 0, 3, 16, 37]))
@@ -26,4 +26,4 @@ for trial in range(40):
     d32 = float((l32 - ref32).abs().max()); d16 = float((l16 - ref16).abs().max())
     worst32, worst16 = max(worst32, d32), max(worst16, d16)
     assert d32 <= 1e-3 and d16 <= 5e-3, (trial, H0, W0, n, pad, order, d32, d16)
-print("40 trials ok: worst |fp32 - oracle| %.3e, worst |bf16 - bf16 oracle| %.3e" % (worst32, worst16))
+print("68 trials ok: worst |fp32 - oracle| %.3e, worst |bf16 - bf16 oracle| %.3e" % (worst32, worst16))
