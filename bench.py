@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 is the headline (the reference's arithmetic); bf16 runs the library's bf16 mode, "
                          "whose logits differ by a few 1e-2 - a separate, non-headline measurement")
+    ap.add_argument("--independent-clips", action="store_true",
+                    help="multi-GPU: every rank segments its own clip (no stream gather, no collective at all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-timing", choices=["dominant", "all", "off"], default="dominant",
                     help="which kernels are bracketed with HIP events inside the timed region: the dominant "
@@ -154,7 +156,7 @@ def main():
     eng.reserve(bs, int(args.height * (256 / args.width)))
     clip = ClipClassifier(eng, n_clip)
     batches = [(a, min(n_clip, a + bs)) for a in range(0, n_clip, bs)]
-    group = dist.group.WORLD if world > 1 else None
+    group = dist.group.WORLD if world > 1 and not args.independent_clips else None
     torch.cuda.synchronize()
 
     def step(i):
@@ -236,7 +238,7 @@ def main():
             "config": {"workload": f"{n_clip} synthetic {args.width}x{args.height} u8 frames per GPU resident in HBM, batch={bs}, "
                                    f"{'fp32' if args.dtype == 'f32' else 'bf16-matrix-core'} prod_net, fused resize+classify, GPU run-length encode, host glue/merge, CSV",
                        "frames_per_gpu_timed": frames_done, "segments_out": int(len(merged["start_frames"])),
-                       "stitch": "all-gather of (class,max) streams over RCCL" if world > 1 else "none"},
+                       "stitch": "all-gather of (class,max) streams over RCCL" if group is not None else "none"},
             "roofline": {
                 "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
                 "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
