@@ -1,4 +1,4 @@
-# Round-end evidence: micro-benchmarks, per-stage bench breakdown, bf16 lines, then the rocprof passes.
+# Full evidence run: micro-benchmarks, per-stage bench breakdown, bf16 lines, then the rocprof passes.
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
