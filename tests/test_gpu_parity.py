@@ -346,12 +346,12 @@ def test_segmentation_class_error_cases(engine, golden_dir):
 
 
 def test_full_size_properties_10k_frames_720p(engine):
-    """Headline-size run (batch 256, 720p) checked through size-independent properties: the class
+    """Headline-size run (10 000 frames, batch 256, 720p) checked through size-independent properties: the class
     stream must equal the generator's labels, segment run lengths must tile the clip, and a second
     pass over the same frames must reproduce every logit bit (the kernels are deterministic)."""
     from cutdet import synth as csynth
     from cutdet.pipeline import ClipClassifier
-    n = 2560
+    n = 10_000                      # the headline configuration: 27.6 GB of frames resident in HBM
     runs = csynth.run_table(n, SEED)
     cl = csynth.classes_from_runs(runs)
     frames = engine.synth_frames(_classes(engine.device, cl), 720, 1280, SEED)
