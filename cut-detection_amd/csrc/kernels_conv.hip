@@ -120,7 +120,8 @@ __device__ __forceinline__ float window_max(const f32x4 (&acc)[3][3]) {
 // (windows enumerated row-major, 16 per tile; only the 256th is padding).  The 11 input rows
 // x 258 columns x 3 channels the tile needs are staged in LDS as fp32, either copied from the
 // normalised NCHW tensor (MODE 0) or produced on the fly from the u8 source frame by the
-// fixed-point bilinear resize (MODE 1), so the resized frame never exists in HBM.
+// resize (MODE 1: pure point sample, MODE 2: fixed-point bilinear / box), so the resized frame
+// never exists in HBM.
 // ------------------------------------------------------------------------------------------
 constexpr int kC1Tile = kInC * kC1Rows * kC1RS;
 
@@ -281,13 +282,11 @@ __device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__
 // MODE 0: fp32 NCHW input.  MODE 1: u8 source, pure point sample (every tap weight is 1).
 // MODE 2: u8 source, general resize.
 //
-// A workgroup walks `cpw` consecutive chunks of one frame, so the per-lane weights and affine
-// terms are fetched once per workgroup.  In MODE 1 the source bytes of chunk k+1 are requested
-// (into registers) during the MFMA work of chunk k, one load instruction per (wave tile, channel
-// group) unit, and are converted and written to LDS after it.  The L1's miss path sustains only a
-// few such gathers per microsecond (each touches ~8 cache lines that all miss), so a burst of 12
-// per wave blocks the issuing waves for ~10 us; spread out, the gathers drain while the matrix
-// cores work and never fill the queue.
+// A workgroup walks `cpw` consecutive chunks of one frame (one by default: with one chunk per
+// workgroup the staging of one workgroup overlaps the MFMA phases of the three others on the CU, and
+// that measured faster than walking several).  When it walks several (CD_C1_CPW > 1), the source
+// bytes of chunk k+1 are requested (into registers) during the MFMA work of chunk k in MODE 1, one
+// load instruction per (wave tile, channel group) unit, and converted and written to LDS after it.
 #ifndef CD_C1_LB
 #define CD_C1_LB 4
 #endif
