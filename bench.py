@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--height", type=int, default=H0, help="source frame height (default: the 720p headline)")
     ap.add_argument("--width", type=int, default=W0, help="source frame width")
+    ap.add_argument("--timing-every", type=int, default=1,
+                    help="with --stage-timing dominant: bracket every n-th launch of the dominant kernel "
+                         "(the roofline's launch time is the average over that sample)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 is the headline (the reference's arithmetic); bf16 runs the library's bf16 mode, "
                          "whose logits differ by a few 1e-2 - a separate, non-headline measurement")
@@ -180,7 +183,7 @@ def main():
 
     # ---- timed region
     if args.stage_timing == "dominant":
-        eng.timing_enable(True, stages=["conv2"])
+        eng.timing_enable(True, stages=["conv2"], every=args.timing_every)
     else:
         eng.timing_enable(args.stage_timing == "all")
     if world > 1:
@@ -214,7 +217,11 @@ def main():
         # sanity: the segmentation of the synthetic clip must recover its long shots
         merged = result["merged"]
         n_launch, ms = timing["conv2"]
-        frames_per_launch = frames_done / max(1, n_launch)
+        # the bracketed launches: every step, or every timing_every-th one counted from the first timed step
+        every = args.timing_every if args.stage_timing == "dominant" else 1
+        sampled = [batches[i % len(batches)] for i in range(args.steps) if i % every == 0]
+        assert n_launch in (0, len(sampled)), (n_launch, len(sampled))
+        frames_per_launch = sum(b - a for a, b in sampled) / max(1, len(sampled))
         conv2_ms = ms / max(1, n_launch)
         achieved = FLOPS_CONV2 * frames_per_launch / (conv2_ms * 1e-3) / 1e12 if n_launch else 0.0
         stages = {k: {"launches": v[0], "ms_total": round(v[1], 3)} for k, v in timing.items() if v[0]}
@@ -243,7 +250,7 @@ def main():
                 "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
                 "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
                 "traffic": traffic, "traffic_unit": "bytes per 256-frame launch (rocprofv3 PMC, profiles/)",
-                "launch_ms": round(conv2_ms, 4), "flops_per_frame": FLOPS_CONV2,
+                "launch_ms": round(conv2_ms, 4), "launches_timed": n_launch, "flops_per_frame": FLOPS_CONV2,
                 "frames_per_launch": round(frames_per_launch, 2),
                 "whole_net_tflops": round(FLOPS_FRAME * fps / world / 1e12, 2),
                 "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps / world / 1e12 / peak_tflops, 4),

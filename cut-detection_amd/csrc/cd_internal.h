@@ -99,6 +99,8 @@ struct cd_handle {
     int rle_blocks_cap;
     // optional per-stage timing: HIP event pairs recorded around each stage's launches
     unsigned timing;   // bit i set: launches of stage i are bracketed
+    int timing_every;  // ... every timing_every-th launch of the stage (1 = all)
+    unsigned timing_seen[CD_STAGE_COUNT];
     std::vector<hipEvent_t> ev_start[CD_STAGE_COUNT], ev_stop[CD_STAGE_COUNT];
     size_t ev_used[CD_STAGE_COUNT];
 };

@@ -256,6 +256,7 @@ struct StageTimer {
     bool live = false;
     StageTimer(cd_handle* h_, int stage_, hipStream_t s_) : h(h_), stage(stage_), s(s_) {
         if (!((h->timing >> stage) & 1u)) return;
+        if (h->timing_seen[stage]++ % (unsigned)(h->timing_every > 0 ? h->timing_every : 1)) return;
         size_t k = h->ev_used[stage];
         if (k == h->ev_start[stage].size()) {
             hipEvent_t a, b;
@@ -484,6 +485,13 @@ int cd_timing_enable(cd_handle* h, int on) {
     // 0 off, 1 every stage, otherwise bit (stage + 1) selects a stage
     h->timing = on == 1 ? ~0u : (unsigned)on >> 1;
     if (!on) for (int st = 0; st < CD_STAGE_COUNT; ++st) h->ev_used[st] = 0;
+    return CD_OK;
+}
+
+int cd_timing_interval(cd_handle* h, int every) {
+    if (!h || every < 1) { set_error("cd_timing_interval: bad argument"); return CD_EINVAL; }
+    h->timing_every = every;
+    for (unsigned& c : h->timing_seen) c = 0;
     return CD_OK;
 }
 

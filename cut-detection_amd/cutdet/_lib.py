@@ -41,6 +41,7 @@ SIGNATURES = {
     "cd_rle": (C.c_int, [_h, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
     "cd_synth_frames": (C.c_int, [_h, _p, _i, _i, _i, _p, C.c_uint32, _l, _p]),
     "cd_timing_enable": (C.c_int, [_h, _i]),
+    "cd_timing_interval": (C.c_int, [_h, _i]),
     "cd_timing_read": (C.c_int, [_h, _i, C.POINTER(_l), C.POINTER(C.c_double)]),
     "cd_glue_segments": (C.c_int, [_p, _p, _p, _p, _p, C.POINTER(_l), _l, _l, _i]),
 }

@@ -174,9 +174,10 @@ class Engine:
         return {"end_frames": end[:s], "frame_types": typ[:s], "run_lengths": rl[:s], "start_frames": st[:s],
                 "score_means": mean[:s], "score_sums": ssum[:s]}
 
-    def timing_enable(self, on=True, stages=None):
-        """Bracket stage launches with HIP events: all stages, or only the named ones (an event pair
-        costs a few microseconds of stream time per launch)."""
+    def timing_enable(self, on=True, stages=None, every=1):
+        """Bracket stage launches with HIP events: all stages, or only the named ones, and only every
+        `every`-th launch of each (an event pair costs a few microseconds of stream time per launch)."""
+        check(lib.cd_timing_interval(self._h, int(every)))
         if on and stages:
             mask = 0
             for name in stages:

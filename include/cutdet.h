@@ -119,6 +119,9 @@ int cd_synth_frames(cd_handle* h, uint8_t* dst, int n, int H0, int W0,
  * duration, and forgets them.
  * No counterpart in the reference; used by bench.py for the per-kernel roofline figures. */
 int cd_timing_enable(cd_handle* h, int on);
+/* Bracket only every `every`-th launch of each selected stage (default 1 = every launch): the
+ * reported totals then cover that sample.  No counterpart in the reference. */
+int cd_timing_interval(cd_handle* h, int every);
 int cd_timing_read(cd_handle* h, int stage, int64_t* launches, double* total_ms);
 
 /* Host-side orphan gluing + adjacent merge on a segment table in host memory, in place.
