@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
 echo trace done
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 40 --warmup 4 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/fetch.err
 echo fetch done
