@@ -79,7 +79,8 @@ def parse():
                     help="which kernels are bracketed with HIP events inside the timed region: the dominant "
                          "one (block 2, what the roofline object reports), every stage (each event pair costs "
                          "a few microseconds of stream time per launch), or none")
-    ap.add_argument("--cpu-sample-batches", type=int, default=10)
+    ap.add_argument("--cpu-sample-batches", type=int, default=40,
+                    help="128-frame batches the CPU baseline times (40 = 5120 frames, about 11 s on 16 host threads)")
     return ap.parse_args()
 
 
