@@ -766,10 +766,11 @@ __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, 
                                            const char* next_src, const int (&rel)[G2<BF>::kDma],
                                            const int (&base)[3], __amdgpu_buffer_rsrc_t wr, int lane,
                                            typename Prec<BF>::frag (&a)[2][3][3], typename Prec<BF>::frag (&b)[2][3],
-                                           f32x4 (&acc)[3][3][3]) {
+                                           f32x4 (&acc)[3][3][3], unsigned long long* st = nullptr) {
     typedef typename Prec<BF>::frag frag;
     typedef typename Prec<BF>::elem elem;
     constexpr int kM = 27 * Prec<BF>::kSub;      // MFMAs per step
+    if (st && lane == 0) st[9] = __builtin_amdgcn_s_memrealtime();
     // everything outstanding was issued at least one step ago
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int bm[3], bo[3];
@@ -788,6 +789,7 @@ __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, 
         // dealt out one per MFMA instead of going out as a block: 3 weight loads, 9 LDS reads and,
         // in step 0, the copies of the next unit's patch (behind the operand loads, so that the
         // wait for those - VMEM completes in order - does not have to cover the copies).
+        if (st && lane == 0) st[kk] = __builtin_amdgcn_s_memrealtime();
         const int n_side = kk == 0 ? 12 + G2<BF>::kDma : 12;
         static_assert(12 + G2<BF>::kDma <= kM, "more memory instructions than MFMAs in a step");
 #pragma unroll
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     // diagnostic build (fp32 only): time stamps of the first 400 waves go to the slack frame behind the batch
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(out + (int64_t)n * out_frame) + 32 * blockIdx.x;
     int nstamp = 0;
-#define CD_STAMP() do { if (!BF && lane == 0 && nstamp < 32 && blockIdx.x < 400) stamps[nstamp] = __builtin_amdgcn_s_memrealtime(); ++nstamp; } while (0)
+#define CD_STAMP() do { if (!BF && lane == 0 && nstamp < 32 && blockIdx.x < 200) stamps[nstamp] = __builtin_amdgcn_s_memrealtime(); ++nstamp; } while (0)
 #else
 #define CD_STAMP() do { } while (0)
 #endif
@@ -956,12 +958,19 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
             for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(a[0][t][j]));
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) asm volatile("" : "+v"(b[0][nt]));
+#ifdef CD_DIAG
+        unsigned long long* stp = (!BF && blockIdx.x < 200 && nstamp == 14) ? stamps + 6400 : nullptr;   // third tile
+        conv2_unit<0, BF>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc, stp);
+        CD_STAMP();
+        conv2_unit<1, BF>(bufs, second, first, cur.src + 2 * kGroupBytes, rel, base, wr, lane, a, b, acc, stp ? stp + 10 : nullptr);
+        CD_STAMP();
+        conv2_unit<2, BF>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc, stp ? stp + 20 : nullptr);
+        CD_STAMP();
+#else
         conv2_unit<0, BF>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc);
-        CD_STAMP();
         conv2_unit<1, BF>(bufs, second, first, cur.src + 2 * kGroupBytes, rel, base, wr, lane, a, b, acc);
-        CD_STAMP();
         conv2_unit<2, BF>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc);
-        CD_STAMP();
+#endif
         // `first` was last read one step ago; the next tile's first unit copies into it only after
         // the epilogue's final LDS wait
         conv2_epilogue<BF>(reinterpret_cast<float*>(bufs + first), acc, spost, cur, Hp, lane);
@@ -1035,7 +1044,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     const int i = lane & 15, kq = lane >> 4;
     const int q = lane >> 4, ch = lane & 15;
 
-#ifdef CD_DIAG
+#ifdef CD_DIAG3   // (shares the slack frame with block 2's stamps: a build of its own, -DCD_DIAG -DCD_DIAG3)
     // diagnostic build: per-wave time stamps go to the slack frame behind the batch's activations
     unsigned long long* st3 = reinterpret_cast<unsigned long long*>(const_cast<elem*>(in) + (int64_t)gridDim.x * (Hin + 2) * kP3W * kC) + (blockIdx.x * 4 + wave) * 8;
     int nst3 = 0;

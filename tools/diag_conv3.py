@@ -1,4 +1,4 @@
-"""Diagnostic: per-wave time stamps of the block-3 + head kernel (needs the CD_DIAG library build)."""
+"""Diagnostic: per-wave time stamps of the block-3 + head kernel (needs a -DCD_DIAG -DCD_DIAG3 library build)."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
