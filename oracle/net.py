@@ -20,9 +20,13 @@ BN_EPS = 1e-5
 
 
 def load_blob(path=_BLOB):
-    """Flat blob -> dict of float32 torch tensors keyed c{l}.w/.b/.g/.beta/.mu/.var, fc0.*, fc1.*"""
+    """Flat blob file -> dict of float32 torch tensors keyed c{l}.w/.b/.g/.beta/.mu/.var, fc0.*, fc1.*"""
     with open(path, "rb") as f:
-        raw = f.read()
+        return load_blob_bytes(f.read())
+
+
+def load_blob_bytes(raw):
+    """The same from the blob's bytes (tests build blobs with random weights)."""
     assert raw[:8] == _MAGIC
     ver, nl, c, cin, ap, ls, no, n = struct.unpack("<8I", raw[8:40])
     flat = np.frombuffer(raw, dtype="<f4", offset=40)

@@ -129,3 +129,47 @@ def test_random_views_both_modes(engines, oracle_weights):
         assert float((l32 - ref32).abs().max()) <= 1e-3, (trial, H0, W0, n, pad, order)
         assert float((l16 - ref16).abs().max()) <= TOL_SAME_ARITHMETIC, (trial, H0, W0, n, pad, order)
         assert float((l16 - ref32).abs().max()) <= 0.25      # random noise frames: larger activations than the clips
+
+
+def test_random_weights_including_negative_batchnorm_scales(oracle_weights):
+    """The bundled net has only positive BatchNorm scales and one set of magnitudes; a random net
+    (negative scales, biased running means, all tensors random) checks the weight packing and the
+    order ReLU -> max-pool -> affine in every block, in both arithmetic modes."""
+    import struct
+    from cutdet import weights as cw
+    from cutdet.engine import Engine
+    from oracle import net as onet
+    rng = np.random.default_rng(5)
+    parts = []
+    for name, shape in cw.tensor_plan():
+        leaf = name.split(".")[-1]
+        if name.endswith("bn.weight"):
+            a = rng.uniform(0.4, 1.5, shape) * rng.choice([-1.0, 1.0], shape)
+        elif leaf == "running_var":
+            a = rng.uniform(0.5, 2.0, shape)
+        elif leaf == "running_mean":
+            a = rng.normal(0.0, 0.3, shape)
+        elif leaf == "weight" and len(shape) >= 2:
+            a = rng.normal(0.0, 1.0 / np.sqrt(np.prod(shape[1:])), shape)
+        else:
+            a = rng.normal(0.0, 0.2, shape)
+        parts.append(np.asarray(a, dtype="<f4").ravel())
+    flat = np.concatenate(parts)
+    blob = open(onet._BLOB, "rb").read()[:8] + struct.pack("<8I", 1, 3, 48, 3, 4, 32, 3, flat.size) + flat.tobytes()
+    w = onet.load_blob_bytes(blob)
+    assert (w["c1.g"] < 0).any() and (w["c0.g"] < 0).any() and (w["fc0.g"] < 0).any()
+    x = torch.from_numpy(rng.random((6, 3, 144, 256), dtype=np.float32))
+    frames = torch.from_numpy(rng.integers(0, 256, size=(5, 720, 1280, 3), dtype=np.uint8))
+    ref32, ref16 = onet.forward(w, x), onet.forward_bf16(w, x)
+    scale = float(ref32.abs().max())
+    for dtype, ref, tol in (("f32", ref32, 1e-3), ("bf16", ref16, TOL_SAME_ARITHMETIC)):
+        eng = Engine(blob, "cuda:0", dtype=dtype)
+        got = eng.forward(x.cuda()).cpu()
+        assert float((got - ref).abs().max()) <= tol * max(1.0, scale), dtype
+        xu = eng.preprocess(frames.cuda())
+        a, b = eng.forward(xu).cpu(), eng.forward_u8(frames.cuda())[0].cpu()
+        if dtype == "f32":
+            assert torch.equal(a, b)             # fused resize = resize then forward, bit for bit
+        else:
+            assert float((a - b).abs().max()) <= tol * max(1.0, scale)   # the fused path rounds the same pixels to bf16
+        eng.close()
