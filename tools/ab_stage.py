@@ -12,11 +12,14 @@ sys.path.insert(0, os.path.join(%r, "cut-detection_amd"))
 import torch
 from cutdet import api
 eng = api.default_engine("cuda:0", %r)
-frames = eng.synth_frames(torch.tensor([i %% 3 for i in range(256)], dtype=torch.uint8, device="cuda"), 720, 1280, 1)
-for _ in range(30): eng.forward_u8(frames)
+# a clip far larger than the caches (like the bench): every batch's source rows come from HBM
+n = 10240
+clip = eng.synth_frames(torch.tensor([i %% 3 for i in range(n)], dtype=torch.uint8, device="cuda"), 720, 1280, 1)
+batches = [clip[a:a + 256] for a in range(0, n, 256)]
+for i in range(40): eng.forward_u8(batches[i %% 40])
 torch.cuda.synchronize()
 eng.timing_enable(True)
-for _ in range(150): eng.forward_u8(frames)
+for i in range(160): eng.forward_u8(batches[i %% 40])
 t = eng.timing_read()
 print(json.dumps({k: v[1] / v[0] * 1e3 for k, v in t.items() if v[0]}))
 '''
