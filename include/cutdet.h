@@ -9,7 +9,9 @@
  *   - every function returns 0 on success and a negative CD_E* code on failure; the message for
  *     the calling thread's last failure is cd_last_error().  Nothing throws across the ABI.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is queued
- *     on it; no call synchronises the device.
+ *     on it.  Steady-state calls do not synchronise; a call that has to grow the workspace or sees
+ *     a new source geometry (other H0 x W0 -> net_h x net_w) synchronises the stream once while it
+ *     re-allocates / uploads its resize tables (cd_reserve() and a first warm-up call avoid both).
  *   - pointers marked "device" must be device memory on the handle's GPU.  Frames, activations
  *     and results are caller-owned; the handle owns the packed weights and an activation
  *     workspace that grows only inside cd_reserve()/the first call that needs more.
@@ -76,8 +78,11 @@ int cd_preprocess(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
 /* prod_net forward on preprocessed frames.
  * Replaces net(batch) at segment_video.py:45 (frameID/net.py:33-40,62-68,122-133) and, through
  * maxv/argmax, torch.max(scores, 1) at frameID/segmentation.py:37.
- * x: device f32 [n][3][net_h][256].  logits: device f32 [n][3].  maxv (f32 [n]) and
- * argmax (i64 [n]) may each be NULL.  Ties resolve to the lowest class index. */
+ * x: device f32 [n][3][net_h][256], net_h in 27..215 (the three 3x3 poolings must leave a row;
+ * above 215 the block-2 activation of one frame no longer fits a CU's LDS).  logits: device
+ * f32 [n][3].  maxv (f32 [n]) and argmax (i64 [n]) may each be NULL.  Ties resolve to the lowest
+ * class index.  The max-pooling ignores a NaN among finite inputs where torch would propagate
+ * it; decoded u8 frames cannot produce one. */
 int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w,
                float* logits, float* maxv, int64_t* argmax, void* stream);
 
