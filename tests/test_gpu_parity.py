@@ -368,3 +368,22 @@ def test_full_size_properties_10k_frames_720p(engine):
     assert res["initial"]["frame_types"].tolist() == [c for c, _ in runs]
     assert res["initial"]["run_lengths"].tolist() == [k for _, k in runs]
     assert int(res["merged"]["run_lengths"].sum()) == n and res["csv"].startswith(b"0,a22\r\n")
+
+
+def test_stage_timing_masks_and_sampling(engine):
+    """cd_timing_enable / cd_timing_interval: only the selected stages are bracketed, only every n-th
+    launch of them, and reading forgets what was read."""
+    frames = engine.synth_frames(_classes(engine.device, [0, 1, 2, 0]), 180, 320, SEED)
+    engine.timing_read()
+    engine.timing_enable(True, stages=["conv2"], every=2)
+    for _ in range(4):
+        engine.forward_u8(frames)
+    t = engine.timing_read()
+    assert t["conv2"][0] == 2 and t["conv2"][1] > 0 and t["conv1"][0] == 0 and t["conv3_head"][0] == 0
+    engine.timing_enable(True)
+    engine.forward_u8(frames)
+    t = engine.timing_read()
+    assert [t[k][0] for k in ("conv1", "conv2", "conv3_head")] == [1, 1, 1]
+    engine.timing_enable(False)
+    engine.forward_u8(frames)
+    assert all(v[0] == 0 for v in engine.timing_read().values())
