@@ -387,3 +387,26 @@ def test_stage_timing_masks_and_sampling(engine):
     engine.timing_enable(False)
     engine.forward_u8(frames)
     assert all(v[0] == 0 for v in engine.timing_read().values())
+
+
+def test_fused_forward_is_hip_graph_capturable(engine):
+    """After one warm-up call (workspace + resize tables in place) the fused forward queues three
+    kernels and nothing else, so it can be captured into a HIP graph and replayed on new frame bytes."""
+    cl = [0, 1, 2] * 8
+    a = engine.synth_frames(_classes(engine.device, cl), 720, 1280, SEED)
+    b = engine.synth_frames(_classes(engine.device, cl[::-1]), 720, 1280, SEED + 1)
+    buf = a.clone()
+    out = (torch.empty((24, 3), device=engine.device), torch.empty((24,), device=engine.device),
+           torch.empty((24,), dtype=torch.int64, device=engine.device))
+    want_a = [t.clone() for t in engine.forward_u8(a)]
+    want_b = [t.clone() for t in engine.forward_u8(b)]
+    engine.forward_u8(buf, out=out)                      # warm-up on the capture buffers
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        engine.forward_u8(buf, out=out)
+    for frames, want in ((b, want_b), (a, want_a)):
+        buf.copy_(frames)
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(out, want))
