@@ -1115,9 +1115,9 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     };
     // Up to three wave tiles (45 windows at 144 input rows) would leave the fourth wave, a quarter of
     // the CU's matrix throughput, idle.  Then (the host passes spare_off >= 0) the K range is split
-    // instead: waves 0-2 run steps 0..19 of their tile, wave 3 runs steps 20..26 of all of them (21
-    // steps) and hands its partial sums over through LDS.
-    constexpr int kSplit = 20;
+    // instead: waves 0-2 run steps 0..20 of their tile, wave 3 runs steps 21..26 of all of them (18
+    // steps, plus the hand-over of its partial sums through LDS; 21 measured best of 19..23).
+    constexpr int kSplit = 21;
     if (spare_off >= 0) {
         if constexpr (!BF) {
             // wave 3 keeps at most two tiles' partial sums in registers: the first tile's go to a
