@@ -1071,8 +1071,8 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     const int fo = tid >> 3, part = tid & 7;
     f32x4 w0[24];
     // 16-byte piece k*8 + part of the output's weight row: the 8 threads of an output read 128
-    // contiguous bytes per load.  Requested when the convolution is over (its accumulators need the
-    // registers) and used three barriers later.
+    // contiguous bytes per load.  Requested when the convolution and its epilogue are over (their
+    // accumulators need the registers) and used two barriers later.
     auto load_fc0 = [&]() {
         const f32x4* wrow = reinterpret_cast<const f32x4*>(fc0w + fo * kFeat) + part;
 #pragma unroll
@@ -1149,13 +1149,13 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
                 }
             }
             __syncthreads();
-            load_fc0();
             if (wave < 3 && wave < wave_tiles) {
                 const f32x4* mine = wave == 0 ? spare : parts + wave * 27 * 64;
 #pragma unroll
                 for (int k = 0; k < 27; ++k) acc[k / 9][(k / 3) % 3][k % 3] += mine[k * 64 + lane];
                 tile_epilogue(wave, acc);
             }
+            load_fc0();
             CD_STAMP3();
         }
     } else {

@@ -19,7 +19,5 @@ assert _lib.lib.cd_debug_peek_act2(eng._h, off, buf.nbytes, buf.ctypes.data_as(C
 s = buf.reshape(n, 4, 8).astype(np.int64)
 t0 = s[:, :, 0].min()
 s = (s - t0) / 100.0
-names = ["start", "patch+params landed", "conv done", "pooled stored", "barrier", "avg-pool barrier", "fc0 barrier", "end"]
 for w in range(4):
-    print("wave %d:" % w, "  ".join("%s %.2f" % (names[k], s[:, w, k].mean()) for k in range(8)))
-print("workgroup end: p50 %.2f max %.2f us" % (np.median(s[:, :, 7].max(axis=1)), s[:, :, 7].max()))
+    print("wave %d stamps (us, mean over workgroups):" % w, " ".join("%.2f" % s[:, w, k].mean() for k in range(8)))
