@@ -193,6 +193,7 @@ int ensure_tables(cd_handle* h, int H0, int W0, int nh, int nw, hipStream_t s) {
     }
     // Tables of the previous geometry may still be in use by queued kernels.
     CD_HIP(hipStreamSynchronize(s));
+    rt.H0 = rt.W0 = rt.h = rt.w = 0;      // nothing valid until every table below is in place
     CD_HIP(hipMemcpy(rt.sx, sx.data(), sx.size() * sizeof(int), hipMemcpyHostToDevice));
     CD_HIP(hipMemcpy(rt.ax, ax.data(), ax.size() * sizeof(short), hipMemcpyHostToDevice));
     CD_HIP(hipMemcpy(rt.sy, sy.data(), sy.size() * sizeof(int), hipMemcpyHostToDevice));
