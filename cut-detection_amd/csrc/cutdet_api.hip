@@ -234,6 +234,9 @@ int ensure_workspace(cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     // a different input height moves the borders: re-zero everything
     CD_HIP(hipMemsetAsync(h->act1, 0, h->act1_bytes, s));
     CD_HIP(hipMemsetAsync(h->act2, 0, h->act2_bytes, s));
+    // The zeroing is complete before this returns: the next call may come on another stream, which
+    // nothing would order behind a memset still queued on this one.
+    CD_HIP(hipStreamSynchronize(s));
     h->ws_h = g.h;
     return CD_OK;
 }

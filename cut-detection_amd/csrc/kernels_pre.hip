@@ -1,4 +1,6 @@
 // Stand-alone resize+normalise kernel and the synthetic clip generator.
+#include <algorithm>
+
 #include "cd_sample.h"
 
 namespace cd {
@@ -155,8 +157,9 @@ int launch_synth(uint8_t* dst, int n, int H0, int W0, const uint8_t* classes, ui
         return CD_EINVAL;
     }
     dim3 grid((unsigned)((elems / 4 + 255) / 256), (unsigned)n), block(256);
+    // stripe period and thickness in source rows (12 and 1 network rows); narrow frames keep a period of 1
     hipLaunchKernelGGL(synth_kernel, grid, block, 0, s, dst, H0, W0, classes, seed, first_index,
-                       (uint32_t)elems, (12 * W0) / 256, (W0 + 255) / 256);
+                       (uint32_t)elems, std::max(1, (12 * W0) / 256), (W0 + 255) / 256);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }

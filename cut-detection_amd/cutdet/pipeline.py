@@ -44,36 +44,54 @@ def csv_bytes(table):
                     for s, t in zip(table["start_frames"], table["frame_types"]))
 
 
-def gather_streams(cls, maxv, group=None):
-    """(cls, maxv) of the whole clip on every rank: each rank's streams all-gathered in rank order.
-    Ranks may hold different counts; payloads are padded to the largest.  Works on any backend
-    (RCCL for GPU tensors, gloo for CPU tensors); without an initialised process group it is the
-    identity."""
+def shard_range(total, rank, world):
+    """Frame range [lo, hi) of `rank` when `total` frames are split into `world` contiguous ranges of
+    ceil(total / world) frames (the last ranges may be short or empty)."""
+    per = -(-int(total) // int(world))
+    return min(total, rank * per), min(total, (rank + 1) * per)
+
+
+def gather_streams(cls, maxv, group=None, total=None):
+    """(cls, maxv) of the whole clip on every rank, from each rank's contiguous frame range, in ONE
+    all-gather.  Ranks own the ranges of shard_range(total, rank, world), so every count is known
+    without asking: `total` defaults to world x this rank's count (equal shards).  Each rank
+    contributes one fixed-size payload, [cap] int64 classes followed by [cap] float32 maxima with
+    cap = ceil(total / world).  Works on any backend (RCCL for GPU tensors, gloo for CPU tensors);
+    without an initialised process group it is the identity."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return cls, maxv
     world = dist.get_world_size(group)
     if world == 1:
         return cls, maxv
+    rank = dist.get_rank(group)
+    n_local = cls.shape[0]
+    total = world * n_local if total is None else int(total)
+    counts = [hi - lo for lo, hi in (shard_range(total, r, world) for r in range(world))]
+    if counts[rank] != n_local or maxv.shape[0] != n_local:
+        raise ValueError(f"rank {rank} holds {n_local} frames; the contiguous split of {total} frames over "
+                         f"{world} ranks gives it {counts[rank]}")
     out_dev = cls.device
     # gloo moves host memory only: stage through the CPU when the group is not RCCL
     dev = out_dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    cls, maxv = cls.to(dev), maxv.to(dev)
-    n_local = cls.shape[0]
-    counts = torch.zeros((world,), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
-    counts = counts.tolist()
     cap = (max(counts) + 1) // 2 * 2          # even, so every rank's 12*cap-byte slot stays 8-byte aligned
-    # one payload per rank: [cap] int64 classes followed by [cap] float32 maxima, as bytes
     pay = torch.zeros((cap * 12,), dtype=torch.uint8, device=dev)
-    pay[: n_local * 8] = cls.contiguous().view(torch.uint8)
-    pay[cap * 8: cap * 8 + n_local * 4] = maxv.contiguous().view(torch.uint8)
+    pay[: n_local * 8] = cls.to(dev).contiguous().view(torch.uint8)
+    pay[cap * 8: cap * 8 + n_local * 4] = maxv.to(dev).contiguous().view(torch.uint8)
     allpay = torch.empty((world * cap * 12,), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(allpay, pay, group=group)
     allpay = allpay.view(world, cap * 12)
     out_cls = torch.cat([allpay[r, : counts[r] * 8].view(torch.int64) for r in range(world)])
     out_max = torch.cat([allpay[r, cap * 8: cap * 8 + counts[r] * 4].view(torch.float32) for r in range(world)])
     return out_cls.to(out_dev), out_max.to(out_dev)
+
+
+def finish_table(initial, real_threshold=100, blank_threshold=10):
+    """Run-length table of the whole clip -> {"initial", "glued", "merged": tables, "csv": bytes}
+    (reference segment_video.py:62-77: glue_orphans, combine_adjacent_segments, write_csv)."""
+    glued = glue_and_merge(initial, real_threshold, blank_threshold, steps=1)
+    merged = glue_and_merge(glued, real_threshold, blank_threshold, steps=2)
+    return {"initial": initial, "glued": glued, "merged": merged, "csv": csv_bytes(merged)}
 
 
 class ClipClassifier:
@@ -94,15 +112,15 @@ class ClipClassifier:
         self.engine.forward_u8(frames_u8, chan_order=chan_order,
                                out=(self.logits[sl], self.maxv[sl], self.cls[sl]))
 
-    def gathered_streams(self, n_local, group=None):
-        return gather_streams(self.cls[:n_local], self.maxv[:n_local], group)
+    def gathered_streams(self, n_local, group=None, total=None):
+        return gather_streams(self.cls[:n_local], self.maxv[:n_local], group, total)
 
-    def segment(self, n_local=None, real_threshold=100, blank_threshold=10, group=None, frame_offset=0):
-        """Segments the (gathered) clip.  Returns {"initial", "glued", "merged": tables, "csv": bytes}."""
+    def segment(self, n_local=None, real_threshold=100, blank_threshold=10, group=None, frame_offset=0,
+                total=None):
+        """Segments the clip: with a process group, this rank's first n_local frames are its range of
+        the `total`-frame clip (see gather_streams) and every rank gets the whole clip's result.
+        Returns {"initial", "glued", "merged": tables, "csv": bytes}."""
         n_local = self.n_frames if n_local is None else int(n_local)
-        cls, mx = self.gathered_streams(n_local, group)
+        cls, mx = self.gathered_streams(n_local, group, total)
         dev = self.engine.rle(cls, mx, frame_offset=frame_offset)
-        initial = {k: dev[k].cpu().numpy() for k in TABLE_KEYS}
-        glued = glue_and_merge(initial, real_threshold, blank_threshold, steps=1)
-        merged = glue_and_merge(glued, real_threshold, blank_threshold, steps=2)
-        return {"initial": initial, "glued": glued, "merged": merged, "csv": csv_bytes(merged)}
+        return finish_table({k: dev[k].cpu().numpy() for k in TABLE_KEYS}, real_threshold, blank_threshold)

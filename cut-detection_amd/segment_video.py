@@ -72,6 +72,8 @@ def main(args):
     net.eval()
     net.to(device)
     logging.info("Loaded default classifier.")
+    # size the activation workspace once, before the first batch, instead of inside it
+    net.engine.reserve(args.batch_size, ds.new_height)
 
     scores, classes, best = [], [], []
     for i, frames in enumerate(ds.frame_batches(args.batch_size)):

@@ -16,6 +16,19 @@
  *     and results are caller-owned; the handle owns the packed weights and an activation
  *     workspace that grows only inside cd_reserve()/the first call that needs more.
  *   - a handle is bound to one device and is not thread-safe; distinct handles are independent.
+ *     Use one stream per handle at a time: consecutive calls on different streams are not ordered
+ *     against each other by the library (the activation workspace is shared by all of them).
+ *
+ * What is pinned against the reference and what is not
+ *   - fp32 forward, max/argmax, run-length tables, glue/merge and CSV are checked against outputs of
+ *     the reference itself (logits to 1e-3, everything else exact; per-segment means are fp64 sums
+ *     rounded once, within 2 ulp of the reference's fp32 torch.mean - a pick between two orphans
+ *     whose means agree to that precision may differ).
+ *   - the resize for geometries other than an odd integer scale (a pure point sample such as
+ *     1280x720 -> 256x144) restates OpenCV's published 8-bit INTER_LINEAR arithmetic without an
+ *     OpenCV build to compare with: parity unpinned.
+ *   - CD_BF16 has no counterpart in the reference: parity unpinned; its logits are within 4.2e-2 of
+ *     the fp32 result on the test clips.
  */
 #ifndef CUTDET_H
 #define CUTDET_H
@@ -64,7 +77,8 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
 void cd_destroy(cd_handle* h);
 
 /* Sizes the activation workspace for batches of up to max_frames frames of network input
- * height net_h (width is always 256).  Optional: the forward calls grow it on demand. */
+ * height net_h (width is always 256).  Optional: the forward calls grow it on demand.  Returns
+ * with the workspace ready (its zeroing has completed), whatever stream the next call uses. */
 int cd_reserve(cd_handle* h, int max_frames, int net_h);
 
 /* Resize + normalise n decoded frames.

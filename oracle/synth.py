@@ -28,7 +28,7 @@ def mix32(x):
 
 def stripe_geometry(width):
     """(period P, thickness T) in source rows for a `width`-pixel-wide source."""
-    return (12 * width) // 256, (width + 255) // 256
+    return max(1, (12 * width) // 256), (width + 255) // 256
 
 
 def frame(seed, index, cls, height, width):

@@ -410,3 +410,33 @@ def test_fused_forward_is_hip_graph_capturable(engine):
         g.replay()
         torch.cuda.synchronize()
         assert all(torch.equal(x, y) for x, y in zip(out, want))
+
+
+# ----------------------------------------------------------------------------- stream discipline
+def test_reserve_then_forward_on_a_side_stream(oracle_weights):
+    """cd_reserve() zeroes the workspace borders; a forward on another (non-blocking) stream right
+    after it must see them zeroed, i.e. give the default-stream result."""
+    from cutdet import api
+    from cutdet.engine import Engine
+    dev = torch.device("cuda", 0)
+    ref_eng = api.default_engine(dev)
+    cl = [0, 1, 2, 1, 0, 2, 1, 0] * 8
+    frames = ref_eng.synth_frames(_classes(dev, cl), 720, 1280, SEED, first_index=11)
+    want = ref_eng.forward_u8(frames)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    for h in (144, 85):
+        eng = Engine(api.default_blob(), dev)
+        # dirty memory first, so that stale borders would show
+        junk = torch.full((int(3e8 // 4),), float("nan"), device=dev)
+        del junk
+        eng.reserve(len(cl), h)
+        with torch.cuda.stream(side):
+            got = eng.forward_u8(frames, net_h=h)
+        side.synchronize()
+        if h == 144:
+            for w, g in zip(want, got):
+                assert torch.equal(w, g)
+        else:
+            assert torch.isfinite(got[0]).all()
+        eng.close()
