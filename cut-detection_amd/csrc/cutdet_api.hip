@@ -4,9 +4,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "cd_internal.h"
+
+// Activations of the allocation-free forward (cd_forward_u8_static): one fixed 32 MiB array per
+// GPU; each device that runs the library holds its own copy, at its own address, until the process ends.
+constexpr size_t kStaticScratchBytes = (size_t)32 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 namespace cd {
 
@@ -241,6 +247,40 @@ int ensure_workspace(cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     return CD_OK;
 }
 
+// ---- activations of the allocation-free forward ----------------------------------------------
+// `scratch` (file scope, above): host code never uses the symbol's name as an address.  cd_create()
+// asks the runtime for the array's device address, once per device with that device current, and
+// everything below works with that pointer.
+constexpr int kMaxDevices = 64;
+struct StaticScratch {
+    unsigned char* ptr = nullptr;   // device address of `scratch` on this GPU
+    int ws_h = 0;                   // network input height its zero borders are laid out for
+};
+StaticScratch g_static[kMaxDevices];
+std::mutex g_static_mutex;
+
+// Layout of the array for one network input height: block-1 activations at offset 0, block-2
+// activations at a fixed offset, both sized for the most frames that fit (plus the slack frame), so
+// that the zero borders sit at the same addresses whatever the batch size.
+struct StaticLayout { int max_frames; size_t act2_off; };
+StaticLayout static_layout(const Geometry& g) {
+    const size_t f1 = (size_t)(g.h1 + 2) * (kW1 + 2) * kC * sizeof(float);
+    const size_t f2 = (size_t)(g.h2 + 2) * (kW2 + 2) * kC * sizeof(float);
+    long m = (long)(kStaticScratchBytes / (f1 + f2));
+    while (m > 0 && align_up((size_t)m * f1, 256) + (size_t)m * f2 > kStaticScratchBytes) --m;
+    return StaticLayout{(int)(m - 1), m > 0 ? align_up((size_t)m * f1, 256) : 0};
+}
+
+int init_static_scratch(int device) {
+    if (device >= kMaxDevices) return CD_OK;       // such a device has no allocation-free entry point
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (g_static[device].ptr) return CD_OK;
+    void* p = nullptr;
+    CD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_static[device].ptr = static_cast<unsigned char*>(p);
+    return CD_OK;
+}
+
 int check_net_shape(const cd_handle* h, int n, int net_h, int net_w, Geometry* g) {
     if (n < 1) { set_error("batch of %d frames", n); return CD_EINVAL; }
     if (net_w != kNetW) { set_error("network input width must be %d, got %d", kNetW, net_w); return CD_EINVAL; }
@@ -352,6 +392,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->rle_blocks), (size_t)h->rle_blocks_cap * sizeof(int64_t)));
 #undef CD_TRY
     if (init_conv3_head() != CD_OK) return fail(CD_EHIP);
+    if (init_static_scratch(device) != CD_OK) return fail(CD_EHIP);
     *out = h;
     return CD_OK;
 }
@@ -437,6 +478,50 @@ int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64
     }
     { StageTimer t(h, CD_STAGE_CONV2, s); if ((rc = launch_conv2(h, n, g, s))) return rc; }
     StageTimer t(h, CD_STAGE_CONV3_HEAD, s);
+    return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
+}
+
+int cd_forward_u8_static(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                         int64_t frame_stride, int chan_order, int net_h, int net_w, float* logits, float* maxv,
+                         int64_t* argmax, void* stream) {
+    if (!h || !logits) { set_error("cd_forward_u8_static: null argument"); return CD_EINVAL; }
+    int rc = check_src("cd_forward_u8_static", src, n, H0, W0, row_stride, frame_stride, chan_order);
+    if (rc) return rc;
+    Geometry g;
+    if ((rc = check_net_shape(h, n, net_h, net_w, &g))) return rc;
+    const StaticLayout lay = static_layout(g);
+    if (n > lay.max_frames) {
+        set_error("cd_forward_u8_static: %d frames of %d rows exceed the %d frames the %zu-byte static "
+                  "activation array holds at that height; use cd_forward_u8", n, net_h, lay.max_frames,
+                  kStaticScratchBytes);
+        return CD_ECAP;
+    }
+    if (h->device >= kMaxDevices || !g_static[h->device].ptr) {
+        set_error("cd_forward_u8_static: no static activation array on device %d", h->device);
+        return CD_EINVAL;
+    }
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    StaticScratch& ss = g_static[h->device];
+    if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;
+    if (ss.ws_h != g.h) {
+        // the array keeps the previous call's contents and another height puts the borders
+        // elsewhere: clear it, and finish before a later call on another stream could overtake
+        CD_HIP(hipMemsetAsync(ss.ptr, 0, kStaticScratchBytes, s));
+        CD_HIP(hipStreamSynchronize(s));
+        ss.ws_h = g.h;
+    }
+    // the kernels take the activation buffers from the handle: lend it the array for this call
+    struct Lend {
+        cd_handle* h; float *a1, *a2;
+        Lend(cd_handle* h_, unsigned char* p, size_t off2) : h(h_), a1(h_->act1), a2(h_->act2) {
+            h->act1 = reinterpret_cast<float*>(p);
+            h->act2 = reinterpret_cast<float*>(p + off2);
+        }
+        ~Lend() { h->act1 = a1; h->act2 = a2; }
+    } lend(h, ss.ptr, lay.act2_off);
+    if ((rc = launch_conv1_u8(h, src, n, H0, W0, row_stride, frame_stride, chan_order, g, s))) return rc;
+    if ((rc = launch_conv2(h, n, g, s))) return rc;
     return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
 }
 

@@ -138,6 +138,19 @@ class Engine:
                                 _ptr(mx), _ptr(am), self._stream()))
         return (logits, mx, am) if want_max else logits
 
+    def forward_u8_static(self, frames, out, chan_order=_lib.CD_BGR, resize=NET_W, net_h=None):
+        """forward_u8 through the library's entry point that allocates nothing: `out` = (logits, max,
+        argmax) must be given, and the batch must fit the library's fixed activation array (34 frames
+        at 144 input rows; CutdetError CD_ECAP beyond).  Calls that overlap on one GPU race."""
+        n, H0, W0, rs, fs = self._frame_layout(frames)
+        nh, nw = output_size(H0, W0, resize)
+        if net_h is not None:
+            nh = int(net_h)
+        logits, mx, am = self._outputs(n, True, out)
+        check(lib.cd_forward_u8_static(self._h, _ptr(frames), n, H0, W0, rs, fs, chan_order, nh, nw, _ptr(logits),
+                                       _ptr(mx), _ptr(am), self._stream()))
+        return logits, mx, am
+
     def max_argmax(self, scores):
         """f32 [n,k] -> (max f32 [n], argmax i64 [n]); torch.max(scores, 1) semantics."""
         self._check_dev(scores, "scores", torch.float32)

@@ -107,6 +107,21 @@ int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
                   int net_h, int net_w,
                   float* logits, float* maxv, int64_t* argmax, void* stream);
 
+/* cd_forward_u8 for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
+ * and results as cd_forward_u8 (bit-identical), but the activations between the blocks live in a
+ * fixed 32 MiB array in the library's device image instead of the handle's workspace, and the call
+ * allocates and frees nothing and records no timing events.  Limit: the batch must fit that array -
+ * 34 frames at a network input height of 144 rows (more at smaller heights); a larger batch returns
+ * CD_ECAP.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (other
+ * streams, other handles, other threads) race.  The first call on a device, and the first after the
+ * input height changed, clears the array and synchronises `stream` once; a new source geometry
+ * uploads the resize tables synchronously, as in cd_forward_u8. */
+int cd_forward_u8_static(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
+                         int64_t row_stride, int64_t frame_stride, int chan_order,
+                         int net_h, int net_w,
+                         float* logits, float* maxv, int64_t* argmax, void* stream);
+
 /* Per-row maximum and its index over scores (device f32 [n][n_classes], row-major).
  * Replaces torch.max(scores, dim=1) at frameID/segmentation.py:37 for callers that hold raw
  * logits.  First maximum wins; a NaN wins over any number (the first NaN), as in torch. */
