@@ -131,6 +131,8 @@ int launch_rle(const cd_handle* h, const int64_t* cls, const float* maxv, int64_
                int64_t* end, int64_t* type, int64_t* runlen, int64_t* start, float* mean, double* sum,
                int64_t cap, int64_t* n_seg, hipStream_t s);
 int launch_max_argmax(const float* scores, int64_t n, int ncls, float* maxv, int64_t* argmax, hipStream_t s);
+int launch_eval_accumulate(const float* logits, const int64_t* labels, int64_t n, int ncls, int64_t* correct,
+                           int64_t* total, double* loss_sum, hipStream_t s);
 int launch_synth(uint8_t* dst, int n, int H0, int W0, const uint8_t* classes, uint32_t seed,
                  int64_t first_index, hipStream_t s);
 

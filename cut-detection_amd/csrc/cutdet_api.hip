@@ -550,6 +550,17 @@ int cd_max_argmax(cd_handle* h, const float* scores, int64_t n, int n_classes, f
     return launch_max_argmax(scores, n, n_classes, maxv, argmax, static_cast<hipStream_t>(stream));
 }
 
+int cd_eval_accumulate(cd_handle* h, const float* logits, const int64_t* labels, int64_t n, int n_classes,
+                       int64_t* correct, int64_t* total, double* loss_sum, void* stream) {
+    if (!h || !logits || !labels || !correct || !total || !loss_sum || n < 1 || n_classes < 1 || n_classes > 8) {
+        set_error("cd_eval_accumulate: null argument, empty batch or more than 8 classes");
+        return CD_EINVAL;
+    }
+    DeviceGuard guard(h->device);
+    return launch_eval_accumulate(logits, labels, n, n_classes, correct, total, loss_sum,
+                                  static_cast<hipStream_t>(stream));
+}
+
 #ifdef CD_DIAG
 // diagnostic builds only: copy bytes out of the block-1 activation workspace
 int cd_debug_peek_act1(cd_handle* h, size_t byte_off, size_t nbytes, void* host_dst) {

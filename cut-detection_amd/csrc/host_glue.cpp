@@ -83,6 +83,7 @@ extern "C" int cd_glue_segments(int64_t* end, int64_t* type, int64_t* runlen, in
             int64_t into;
             if (p < 0) {
                 if (n < 0) {   // the reference indexes row 1 of a one-row table here
+                    if (steps & 4) break;          // opt-in guard: keep the lone segment
                     cd::set_error("index out of bounds: one orphan segment left, nothing to glue it to");
                     return CD_EINVAL;
                 }

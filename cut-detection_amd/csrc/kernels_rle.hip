@@ -127,6 +127,56 @@ __global__ __launch_bounds__(256) void max_argmax_kernel(const float* __restrict
     argmax[i] = bi;
 }
 
+// Per-class correct / total counts and the summed cross-entropy of one labelled batch
+// (reference training_scripts/supervised_training.py:186-201).  One frame per lane; counts leave a
+// wave as ballots + popcounts, the loss as an fp64 butterfly sum, one atomic per wave and quantity.
+__global__ __launch_bounds__(256) void eval_accumulate_kernel(const float* __restrict__ logits,
+                                                              const int64_t* __restrict__ labels, int64_t n, int ncls,
+                                                              unsigned long long* __restrict__ correct,
+                                                              unsigned long long* __restrict__ total,
+                                                              double* __restrict__ loss_sum) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int label = -1, pred = -2;
+    double loss = 0.0;
+    if (i < n) {
+        const int64_t l = labels[i];
+        const float* r = logits + i * ncls;
+        float best = r[0];
+        int bi = 0;
+        for (int o = 1; o < ncls; ++o) {
+            const float v = r[o];
+            if (!(best != best) && (v > best || v != v)) { best = v; bi = o; }
+        }
+        if (l >= 0 && l < ncls) {
+            label = (int)l;
+            pred = bi;
+            // -log_softmax(r)[label] = log(sum exp(r - max)) + max - r[label]
+            double se = 0.0;
+            for (int o = 0; o < ncls; ++o) se += exp((double)r[o] - (double)best);
+            loss = log(se) + (double)best - (double)r[label];
+        }
+    }
+    for (int c = 0; c < ncls; ++c) {
+        const unsigned long long mt = __ballot(label == c), mc = __ballot(label == c && pred == c);
+        if (lane == 0) {
+            if (mt) atomicAdd(total + c, (unsigned long long)__popcll(mt));
+            if (mc) atomicAdd(correct + c, (unsigned long long)__popcll(mc));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+    if (lane == 0 && loss != 0.0) atomicAdd(loss_sum, loss);
+}
+
+int launch_eval_accumulate(const float* logits, const int64_t* labels, int64_t n, int ncls, int64_t* correct,
+                           int64_t* total, double* loss_sum, hipStream_t s) {
+    hipLaunchKernelGGL(eval_accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, logits, labels, n,
+                       ncls, reinterpret_cast<unsigned long long*>(correct),
+                       reinterpret_cast<unsigned long long*>(total), loss_sum);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
 int launch_max_argmax(const float* scores, int64_t n, int ncls, float* maxv, int64_t* argmax, hipStream_t s) {
     hipLaunchKernelGGL(max_argmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, ncls, maxv,
                        argmax);

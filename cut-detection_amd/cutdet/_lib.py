@@ -39,6 +39,7 @@ SIGNATURES = {
     "cd_forward_u8": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),
     "cd_forward_u8_static": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),
     "cd_max_argmax": (C.c_int, [_h, _p, _l, _i, _p, _p, _p]),
+    "cd_eval_accumulate": (C.c_int, [_h, _p, _p, _l, _i, _p, _p, _p, _p]),
     "cd_rle": (C.c_int, [_h, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
     "cd_synth_frames": (C.c_int, [_h, _p, _i, _i, _i, _p, C.c_uint32, _l, _p]),
     "cd_timing_enable": (C.c_int, [_h, _i]),

@@ -164,6 +164,24 @@ class Engine:
             check(lib.cd_max_argmax(self._h, _ptr(scores), n, k, _ptr(mx), _ptr(am), self._stream()))
         return mx, am
 
+    def eval_accumulate(self, logits, labels, correct, total, loss_sum):
+        """Adds one labelled batch to the validation accumulators (device tensors: correct, total i64
+        [classes], loss_sum f64 [1]); see cd_eval_accumulate."""
+        self._check_dev(logits, "logits", torch.float32)
+        self._check_dev(labels, "labels", torch.int64)
+        self._check_dev(correct, "correct", torch.int64)
+        self._check_dev(total, "total", torch.int64)
+        self._check_dev(loss_sum, "loss_sum", torch.float64)
+        if logits.dim() != 2 or labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+            raise ValueError("logits must be [n, k] and labels [n]")
+        k = logits.shape[1]
+        if correct.numel() != k or total.numel() != k or loss_sum.numel() != 1:
+            raise ValueError("accumulators must hold one count per class and one loss sum")
+        logits, labels = logits.contiguous(), labels.contiguous()
+        if logits.shape[0]:
+            check(lib.cd_eval_accumulate(self._h, _ptr(logits), _ptr(labels), logits.shape[0], k, _ptr(correct),
+                                         _ptr(total), _ptr(loss_sum), self._stream()))
+
     def rle(self, cls, maxv, frame_offset=0, cap=None):
         """Class stream -> dict of device tensors (end_frames, frame_types, run_lengths, start_frames,
         score_means, score_sums) trimmed to the number of segments.  Synchronises to read the count."""

@@ -18,12 +18,14 @@ from . import _lib
 
 CLASS_NAMES = ("a22", "ez", "b")   # ids 0, 1, 2 (reference frameID/data.py:116)
 TABLE_KEYS = ("end_frames", "frame_types", "run_lengths", "start_frames", "score_means")
+GLUE, MERGE, KEEP_LONE_ORPHAN = 1, 2, 4     # `steps` bits of cd_glue_segments
 
 
 def glue_and_merge(table, real_threshold=100, blank_threshold=10, steps=3):
     """Host pass over a segment table {key: numpy array}; returns a new table.
     steps: bit 0 glue orphans (reference segmentation.py:91-166), bit 1 merge equal
-    neighbours (:168-183).  Raises IndexError where the reference does."""
+    neighbours (:168-183), bit 2 (KEEP_LONE_ORPHAN) keep a clip that collapses to one short
+    segment.  Without bit 2 it raises IndexError where the reference does."""
     a = {k: np.ascontiguousarray(table[k]).copy() for k in TABLE_KEYS}
     n = C.c_int64(a["end_frames"].shape[0])
     p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
@@ -38,10 +40,74 @@ def glue_and_merge(table, real_threshold=100, blank_threshold=10, steps=3):
     return {k: a[k][: n.value] for k in TABLE_KEYS}
 
 
-def csv_bytes(table):
-    """`start,type` rows with CRLF line ends and no header (reference segmentation.py:185-196)."""
-    return b"".join(b"%d,%s\r\n" % (int(s), CLASS_NAMES[int(t)].encode())
-                    for s, t in zip(table["start_frames"], table["frame_types"]))
+# CSV columns: the reference writes the first two and nothing else (segmentation.py:185-196)
+DEFAULT_COLUMNS = ("start", "type")
+COLUMNS = ("start", "type", "end_frame", "run_length", "score_mean")
+
+
+def check_columns(columns):
+    columns = tuple(columns)
+    bad = [c for c in columns if c not in COLUMNS]
+    if bad or not columns:
+        raise ValueError(f"unknown CSV column(s) {bad}; choose from {COLUMNS}")
+    return columns
+
+
+def csv_rows(table, columns=DEFAULT_COLUMNS):
+    """Rows of a segment table as tuples of str, one field per requested column.  `score_mean`
+    is written with 9 significant digits (enough to restore the float32)."""
+    columns = check_columns(columns)
+    src = {"start": ("start_frames", lambda v: "%d" % int(v)),
+           "type": ("frame_types", lambda v: CLASS_NAMES[int(v)]),
+           "end_frame": ("end_frames", lambda v: "%d" % int(v)),
+           "run_length": ("run_lengths", lambda v: "%d" % int(v)),
+           "score_mean": ("score_means", lambda v: "%.9g" % float(v))}
+    cols = [[fmt(v) for v in table[key]] for key, fmt in (src[c] for c in columns)]
+    return list(zip(*cols))
+
+
+def csv_bytes(table, columns=DEFAULT_COLUMNS):
+    """CSV text of a segment table: CRLF line ends, no header.  The default columns give the
+    reference's file byte for byte (`start,type`, segmentation.py:185-196)."""
+    return b"".join((",".join(r) + "\r\n").encode() for r in csv_rows(table, columns))
+
+
+class SegmentCsvStream:
+    """One CSV for many clips, written as the clips finish (the multi-clip throughput mode: every
+    GPU segments its own clips and appends to a file of its own or, through a lock held by the
+    caller, to a shared one).  Rows are `clip,<columns...>`; each clip's rows are written and
+    flushed in one piece, so a reader following the file never sees half a clip."""
+
+    def __init__(self, path_or_file, columns=DEFAULT_COLUMNS, clip_column=True):
+        self.columns = check_columns(columns)
+        self.clip_column = bool(clip_column)
+        self._own = isinstance(path_or_file, (str, bytes)) or hasattr(path_or_file, "__fspath__")
+        self._f = open(path_or_file, "ab") if self._own else path_or_file
+        self.clips = 0
+        self.rows = 0
+
+    def write_clip(self, clip_id, table):
+        rows = csv_rows(table, self.columns)
+        if self.clip_column:
+            cid = str(clip_id)
+            if any(ch in cid for ch in ',"\r\n'):
+                cid = '"' + cid.replace('"', '""') + '"'
+            rows = [(cid,) + r for r in rows]
+        self._f.write(b"".join((",".join(r) + "\r\n").encode() for r in rows))
+        self._f.flush()
+        self.clips += 1
+        self.rows += len(rows)
+
+    def close(self):
+        if self._own and self._f is not None:
+            self._f.close()
+        self._f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def shard_range(total, rank, world):
@@ -86,12 +152,13 @@ def gather_streams(cls, maxv, group=None, total=None):
     return out_cls.to(out_dev), out_max.to(out_dev)
 
 
-def finish_table(initial, real_threshold=100, blank_threshold=10):
+def finish_table(initial, real_threshold=100, blank_threshold=10, keep_lone_orphan=False, columns=DEFAULT_COLUMNS):
     """Run-length table of the whole clip -> {"initial", "glued", "merged": tables, "csv": bytes}
     (reference segment_video.py:62-77: glue_orphans, combine_adjacent_segments, write_csv)."""
-    glued = glue_and_merge(initial, real_threshold, blank_threshold, steps=1)
-    merged = glue_and_merge(glued, real_threshold, blank_threshold, steps=2)
-    return {"initial": initial, "glued": glued, "merged": merged, "csv": csv_bytes(merged)}
+    glued = glue_and_merge(initial, real_threshold, blank_threshold,
+                           steps=GLUE | (KEEP_LONE_ORPHAN if keep_lone_orphan else 0))
+    merged = glue_and_merge(glued, real_threshold, blank_threshold, steps=MERGE)
+    return {"initial": initial, "glued": glued, "merged": merged, "csv": csv_bytes(merged, columns)}
 
 
 class ClipClassifier:

@@ -71,6 +71,73 @@ class ProdNet:
         `net_h`: see cutdet.Engine.forward_u8 (frames already reduced to their sampled rows)."""
         return self.engine.forward_u8(frames_u8, chan_order=chan_order, net_h=net_h)
 
+    # --- training-side reuse ------------------------------------------------------------------
+    def evaluate(self, batches, chan_order=0):
+        """The validation pass of the reference's training script
+        (training_scripts/supervised_training.py:177-215) on the fused forward: `batches` yields
+        `(x, labels)` pairs or the reference loader's `{"x": ..., "y": ...}` dicts, x being float
+        frames [B,3,H,256] or decoded u8 frames [B,H0,W0,3], labels int64 class ids.  Counting and
+        the cross-entropy run on the GPU (cd_eval_accumulate).  Returns a dict: `correct`, `total`
+        (per class, ints), `accuracy` (per class, correct/total as the script logs it; nan for a
+        class without frames), `loss` (mean cross-entropy per frame), `frames`."""
+        val = Validation(self)
+        for item in batches:
+            x, y = (item["x"], item["y"]) if isinstance(item, dict) else item
+            val.update(x, y, chan_order=chan_order)
+        return val.result()
+
+    def state_dicts(self):
+        """(conv_state_dict, linear_state_dict) of torch tensors with the reference's tensor names
+        (frameID/net.py FrameConvNet / FrameLinearNet), BatchNorm counters included (as zero: the
+        weight blob does not keep them and inference never reads them)."""
+        conv, lin = {}, {}
+        for name, arr in weights.unpack_blob(self._blob).items():
+            (conv if name.startswith("conv_layers.") else lin)[name] = torch.from_numpy(arr.copy())
+            if name.endswith("bn.running_var"):
+                (conv if name.startswith("conv_layers.") else lin)[name.replace("running_var", "num_batches_tracked")] = \
+                    torch.tensor(0, dtype=torch.int64)
+        return conv, lin
+
+    def save_reference_files(self, param_file, conv_file, linear_file):
+        """Writes the three files `load_and_glue_nets` (here and in the reference, net.py:193-217)
+        reads: the JSON hyper-parameters and the two state dicts, as
+        supervised_training.py:224-245 saves them."""
+        conv, lin = self.state_dicts()
+        torch.save(conv, conv_file)
+        torch.save(lin, linear_file)
+        with open(param_file, "w") as f:
+            json.dump(self.params, f)
+
+
+class Validation:
+    """Per-class correct / total counts and the summed cross-entropy of labelled batches, kept on
+    the GPU until `result()` (reference training_scripts/supervised_training.py:177-215)."""
+
+    def __init__(self, net, n_classes=3):
+        self.net = net
+        dev = net.engine.device
+        self.correct = torch.zeros((n_classes,), dtype=torch.int64, device=dev)
+        self.total = torch.zeros((n_classes,), dtype=torch.int64, device=dev)
+        self.loss_sum = torch.zeros((1,), dtype=torch.float64, device=dev)
+
+    def update(self, x, labels, chan_order=0):
+        eng = self.net.engine
+        x = x.to(eng.device)
+        if x.dtype == torch.uint8:
+            logits = eng.forward_u8(x, chan_order=chan_order, want_max=False)
+        else:
+            logits = eng.forward(x)
+        labels = labels.to(device=eng.device, dtype=torch.int64).reshape(-1)      # the script squeezes [B,1] -> [B]
+        eng.eval_accumulate(logits, labels, self.correct, self.total, self.loss_sum)
+        return logits
+
+    def result(self):
+        correct, total = self.correct.cpu().tolist(), self.total.cpu().tolist()
+        frames = sum(total)
+        return {"correct": correct, "total": total,
+                "accuracy": [c / t if t else float("nan") for c, t in zip(correct, total)],
+                "loss": float(self.loss_sum.item()) / frames if frames else float("nan"), "frames": frames}
+
 
 # Function to slightly simplify loading networks and making a single callable.
 def load_and_glue_nets(param_file, conv_file, linear_file, dtype="f32"):

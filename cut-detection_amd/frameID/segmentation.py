@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from cutdet import _lib, api
+from cutdet.pipeline import DEFAULT_COLUMNS, KEEP_LONE_ORPHAN, csv_rows
 
 from .data import SupervisedFrameDataset
 
@@ -74,16 +75,20 @@ class Segmentation:
     def __len__(self):
         return self.te["end_frames"].shape[0]
 
-    def glue_orphans(self, real_threshold=100, blank_threshold=10):
-        self.te = _host_pass(self.te, real_threshold, blank_threshold, GLUE)
+    def glue_orphans(self, real_threshold=100, blank_threshold=10, keep_lone_orphan=False):
+        """Glue short segments into a neighbour, least confident first (reference :91-166).  A clip
+        that collapses to one segment that is still short raises IndexError, as the reference does
+        (:110-116 index row 1 of a one-row table); `keep_lone_orphan=True` keeps that segment."""
+        self.te = _host_pass(self.te, real_threshold, blank_threshold,
+                             GLUE | (KEEP_LONE_ORPHAN if keep_lone_orphan else 0))
 
     def combine_adjacent_segments(self):
         """Combine adjacent segments of the same type."""
         self.te = _host_pass(self.te, 0, 0, MERGE)
 
-    def write_csv(self, file_path):
-        """`start_frame,type` rows, CRLF line ends, no header (reference :185-196)."""
+    def write_csv(self, file_path, columns=DEFAULT_COLUMNS):
+        """`start_frame,type` rows, CRLF line ends, no header (reference :185-196).  `columns` may add
+        `end_frame`, `run_length` and `score_mean` (see cutdet.pipeline.COLUMNS)."""
+        table = {k: v.numpy() for k, v in self.te.items()}
         with open(file_path, "w", newline="") as f:
-            out = csv.writer(f, delimiter=",")
-            for start, kind in zip(self.te["start_frames"].tolist(), self.te["frame_types"].tolist()):
-                out.writerow((start, _INVERSE_TYPE_MAP[kind]))
+            csv.writer(f, delimiter=",").writerows(csv_rows(table, columns))

@@ -23,6 +23,7 @@ import torch  # noqa: E402
 from frameID.data import VideoDataset  # noqa: E402
 from frameID.net import load_default_net  # noqa: E402
 from frameID.segmentation import Segmentation  # noqa: E402
+from cutdet.pipeline import COLUMNS, SegmentCsvStream, check_columns  # noqa: E402
 
 logging.basicConfig(
     level="INFO",
@@ -51,34 +52,27 @@ def build_parser():
     p.add_argument("--device", type=str, default="cuda:0", help="GPU to run on.")
     p.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                    help="Arithmetic of the classifier: f32 (the reference's) or bf16 matrix cores.")
+    p.add_argument("--columns", type=str, default="start,type",
+                   help=f"CSV columns, comma separated, from {','.join(COLUMNS)} (default: the reference's start,type).")
+    p.add_argument("--keep-lone-orphan", action="store_true",
+                   help="A clip that collapses to one short segment is written as that segment instead of failing.")
+    p.add_argument("--more-inputs", type=str, nargs="*", default=[],
+                   help="More videos: all clips go to ONE csv (output_path, default <first input>_segments.csv) "
+                        "with a leading clip column, each clip's rows appended as soon as it is done.")
     return p
 
 
 sv_parser = build_parser()
 
 
-def main(args):
-    if not os.path.isfile(args.input_path):
-        raise ValueError(f"{args.input_path} does not exist.")
-    if args.cpu:
-        raise RuntimeError("--cpu: this build has no CPU classifier; run on an MI355X")
-    if not torch.cuda.is_available():
-        raise RuntimeError("no GPU visible: this build runs the classifier on an MI355X only")
-    device = getattr(args, "device", "cuda:0")
-    logging.info(f"Using {device}")
-
-    ds = VideoDataset(args.input_path, resize=256, device=device)
-    net, params = load_default_net(getattr(args, "dtype", "f32"))
-    net.eval()
-    net.to(device)
-    logging.info("Loaded default classifier.")
+def segment_one(path, net, args, device):
+    """Classifies and segments one video; returns the Segmentation (reference segment_video.py:28-66)."""
+    ds = VideoDataset(path, resize=256, device=device)
     # size the activation workspace once, before the first batch, instead of inside it
-    net.engine.reserve(args.batch_size, ds.new_height)
-
-    scores, classes, best = [], [], []
+    net.engine.reserve(args.batch_size, ds.batch_net_height or ds.new_height)
+    classes, best = [], []
     for i, frames in enumerate(ds.frame_batches(args.batch_size)):
-        logits, mx, am = net.classify_frames(frames, chan_order=ds.chan_order, net_h=ds.batch_net_height)
-        scores.append(logits)
+        _, mx, am = net.classify_frames(frames, chan_order=ds.chan_order, net_h=ds.batch_net_height)
         best.append(mx)
         classes.append(am)
         if args.print_every > 0 and i % args.print_every == args.print_every - 1:
@@ -86,22 +80,55 @@ def main(args):
         # same stopping rule as the reference: the batch that crosses the limit is still scored
         if args.frame_limit is not None and (i + 1) * args.batch_size > args.frame_limit:
             break
-    if not scores:
+    if not classes:
         raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
 
     seg = Segmentation.from_stream(torch.cat(classes), torch.cat(best))
     logging.info(f"Found {len(seg)} initial segments")
-    seg.glue_orphans(args.base_threshold, args.blank_threshold)
+    seg.glue_orphans(args.base_threshold, args.blank_threshold,
+                     keep_lone_orphan=getattr(args, "keep_lone_orphan", False))
     logging.info(f"Revised to {len(seg)} segments through orphan combination.")
     seg.combine_adjacent_segments()
     logging.info(f"Revised to {len(seg)} segments through matching adjacent combination.")
+    return seg
+
+
+def main(args):
+    inputs = [args.input_path] + list(getattr(args, "more_inputs", None) or [])
+    for path in inputs:
+        if not os.path.isfile(path):
+            raise ValueError(f"{path} does not exist.")
+    if args.cpu:
+        raise RuntimeError("--cpu: this build has no CPU classifier; run on an MI355X")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: this build runs the classifier on an MI355X only")
+    columns = check_columns(getattr(args, "columns", "start,type").split(","))
+    device = getattr(args, "device", "cuda:0")
+    logging.info(f"Using {device}")
+
+    net, params = load_default_net(getattr(args, "dtype", "f32"))
+    net.eval()
+    net.to(device)
+    logging.info("Loaded default classifier.")
 
     if args.output_path is None:
         out_path = os.path.splitext(args.input_path)[0] + "_segments.csv"
     else:
         out_path = args.output_path
-    logging.info(f"Writing {len(seg)} segments to {out_path}")
-    seg.write_csv(out_path)
+
+    if len(inputs) == 1:
+        seg = segment_one(args.input_path, net, args, device)
+        logging.info(f"Writing {len(seg)} segments to {out_path}")
+        seg.write_csv(out_path, columns)
+        return out_path
+
+    # several clips: one CSV, each clip appended (and flushed) when it is done
+    open(out_path, "wb").close()
+    with SegmentCsvStream(out_path, columns) as stream:
+        for path in inputs:
+            seg = segment_one(path, net, args, device)
+            stream.write_clip(os.path.basename(path), {k: v.numpy() for k, v in seg.te.items()})
+            logging.info(f"Appended {len(seg)} segments of {path} to {out_path}")
     return out_path
 
 

@@ -128,6 +128,18 @@ int cd_forward_u8_static(cd_handle* h, const uint8_t* src, int n, int H0, int W0
 int cd_max_argmax(cd_handle* h, const float* scores, int64_t n, int n_classes,
                   float* maxv, int64_t* argmax, void* stream);
 
+/* Validation bookkeeping for one batch of labelled frames, accumulated on the device.
+ * Replaces the body of the validation loop at training_scripts/supervised_training.py:186-201:
+ * pc = torch.max(pred, 1)[1]; correct[c] += #(label == c and pc == c); total[c] += #(label == c);
+ * plus the summed cross-entropy of pred against the labels (nn.CrossEntropyLoss, summed over
+ * frames rather than averaged per batch).  logits: device f32 [n][n_classes] (n_classes <= 8);
+ * labels: device i64 [n], a label outside 0..n_classes-1 is skipped.  correct, total: device
+ * i64 [n_classes]; loss_sum: device f64 [1]; all three are added to, not overwritten (the order of
+ * the fp64 additions across wavefronts is not fixed). */
+int cd_eval_accumulate(cd_handle* h, const float* logits, const int64_t* labels, int64_t n,
+                       int n_classes, int64_t* correct, int64_t* total, double* loss_sum,
+                       void* stream);
+
 /* Run-length encodes a per-frame class stream into segments.
  * Replaces frameID/segmentation.py:39-60 (Segmentation.__init__ after the max).
  * cls (i64 [n]) and maxv (f32 [n]) are device arrays.  Outputs are device arrays of capacity
@@ -161,9 +173,10 @@ int cd_timing_read(cd_handle* h, int stage, int64_t* launches, double* total_ms)
 /* Host-side orphan gluing + adjacent merge on a segment table in host memory, in place.
  * Replaces frameID/segmentation.py:91-166 glue_orphans() and :168-183
  * combine_adjacent_segments().  Arrays hold *n_seg rows on entry; on return *n_seg is the new
- * row count.  steps: bit 0 = glue orphans, bit 1 = merge adjacent.
+ * row count.  steps: bit 0 = glue orphans, bit 1 = merge adjacent, bit 2 = keep a lone orphan.
  * Returns CD_EINVAL with message "index out of bounds" where the reference raises IndexError
- * (the table collapsed to a single segment that is still an orphan). */
+ * (segmentation.py:110-116: the table collapsed to a single segment that is still an orphan);
+ * with bit 2 set that segment is kept instead and the call succeeds. */
 int cd_glue_segments(int64_t* end, int64_t* type, int64_t* runlen, int64_t* start, float* mean,
                      int64_t* n_seg, int64_t real_threshold, int64_t blank_threshold, int steps);
 

@@ -215,3 +215,147 @@ def test_product_code_never_touches_the_oracle_or_a_cpu_network():
             if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or re.search(r"\bconv2d\b|\bmax_pool2d\b|nn\.Conv2d", text):
                 offenders.append(os.path.join(dirpath, f))
     assert offenders == []
+
+
+# ----------------------------------------------------------------------------- wire format
+def test_csv_columns_and_default_bytes(golden_dir):
+    from cutdet import pipeline
+    c = _load_seg(golden_dir)["ten_runs"]
+    t = _table(c["merged"])
+    assert pipeline.csv_bytes(t) == base64.b64decode(c["csv_b64"])              # default = the reference's bytes
+    assert pipeline.csv_bytes(t, ("start", "type")) == base64.b64decode(c["csv_b64"])
+    full = pipeline.csv_bytes(t, pipeline.COLUMNS).decode().split("\r\n")
+    assert full[-1] == "" and len(full) == len(t["start_frames"]) + 1
+    for row, s, k, e, n, m in zip(full, t["start_frames"], t["frame_types"], t["end_frames"], t["run_lengths"],
+                                  t["score_means"]):
+        f = row.split(",")
+        assert (int(f[0]), f[1], int(f[2]), int(f[3])) == (s, pipeline.CLASS_NAMES[k], e, n)
+        assert np.float32(f[4]) == m                                           # 9 digits restore the float32
+    with pytest.raises(ValueError):
+        pipeline.csv_bytes(t, ("start", "colour"))
+    with pytest.raises(ValueError):
+        pipeline.csv_bytes(t, ())
+
+
+def test_streaming_csv_appends_whole_clips(golden_dir, tmp_path):
+    from cutdet import pipeline
+    cases = _load_seg(golden_dir)
+    p = tmp_path / "all.csv"
+    with pipeline.SegmentCsvStream(str(p), ("start", "type", "end_frame")) as st:
+        st.write_clip("game 1.mp4", _table(cases["ten_runs"]["merged"]))
+        seen = p.read_bytes()                                                   # flushed clip by clip
+        st.write_clip("a,b.mp4", _table(cases["chain_merge"]["merged"]))
+        assert st.clips == 2
+    data = p.read_bytes()
+    assert data.startswith(seen) and seen.count(b"\r\n") == len(cases["ten_runs"]["merged"]["start_frames"])
+    import csv
+    import io
+    rows = list(csv.reader(io.StringIO(data.decode(), newline="")))
+    assert {r[0] for r in rows} == {"game 1.mp4", "a,b.mp4"} and all(len(r) == 4 for r in rows)
+    t = _table(cases["ten_runs"]["merged"])
+    first = [r for r in rows if r[0] == "game 1.mp4"]
+    assert [int(r[1]) for r in first] == t["start_frames"].tolist() and [int(r[3]) for r in first] == t["end_frames"].tolist()
+    # without the clip column a single clip's stream equals the one-shot file
+    q = tmp_path / "one.csv"
+    with pipeline.SegmentCsvStream(str(q), clip_column=False) as st:
+        st.write_clip(0, t)
+    assert q.read_bytes() == base64.b64decode(cases["ten_runs"]["csv_b64"])
+
+
+# ----------------------------------------------------------------------------- lone-orphan guard, scale
+@pytest.mark.parametrize("name", ["single_short_segment", "all_orphans"])
+def test_lone_orphan_guard_is_opt_in(golden_dir, name):
+    from cutdet import pipeline
+    c = _load_seg(golden_dir)[name]
+    init = _table(c["init"])
+    with pytest.raises(IndexError):                                             # default: the reference's IndexError
+        pipeline.glue_and_merge(init, *c["thresholds"], steps=pipeline.GLUE)
+    kept = pipeline.glue_and_merge(init, *c["thresholds"], steps=pipeline.GLUE | pipeline.KEEP_LONE_ORPHAN)
+    assert len(kept["start_frames"]) == 1
+    assert kept["start_frames"][0] == init["start_frames"][0] and kept["end_frames"][0] == init["end_frames"][-1]
+    assert kept["run_lengths"][0] == init["run_lengths"].sum()
+    out = pipeline.finish_table(init, *c["thresholds"], keep_lone_orphan=True)
+    assert out["csv"].count(b"\r\n") == 1
+    # the guard changes nothing when the reference does not fail
+    ok = _load_seg(golden_dir)["ten_runs"]
+    a = pipeline.glue_and_merge(_table(ok["init"]), *ok["thresholds"], steps=3)
+    b = pipeline.glue_and_merge(_table(ok["init"]), *ok["thresholds"], steps=7)
+    assert all(a[k].tobytes() == b[k].tobytes() for k in pipeline.TABLE_KEYS)
+
+
+def _random_table(rs, n):
+    lens = rs.choice([1, 3, 8, 9, 10, 40, 99, 100, 101, 250, 600], size=n)
+    types = rs.randint(0, 3, size=n)
+    for i in range(1, n):
+        if types[i] == types[i - 1]:
+            types[i] = (types[i] + 1) % 3
+    ends = np.cumsum(lens) - 1
+    return {"end_frames": ends.astype(np.int64), "frame_types": types.astype(np.int64),
+            "run_lengths": lens.astype(np.int64), "start_frames": (ends - lens + 1).astype(np.int64),
+            "score_means": rs.uniform(1, 9, size=n).astype(np.float32)}
+
+
+def test_glue_scales_to_100k_segments():
+    """100 000 segments through the heap-based pass in well under a second; its first 2 000
+    segments, as a table of their own, agree with the oracle's quadratic loop bit for bit."""
+    import time
+    from cutdet import pipeline
+    from oracle import segmentation
+    rs = np.random.RandomState(3)
+    big = _random_table(rs, 100_000)
+    t0 = time.perf_counter()
+    out = pipeline.glue_and_merge(big, 100, 10)
+    dt = time.perf_counter() - t0
+    assert dt < 2.0, f"{dt:.2f} s for 100 000 segments"
+    assert 0 < len(out["start_frames"]) < 100_000
+    assert (out["run_lengths"] == out["end_frames"] - out["start_frames"] + 1).all()
+    assert out["start_frames"][0] == 0 and out["end_frames"][-1] == big["end_frames"][-1]
+    assert (out["start_frames"][1:] == out["end_frames"][:-1] + 1).all()
+    assert (out["frame_types"][1:] != out["frame_types"][:-1]).all()
+    small = {k: v[:2000].copy() for k, v in big.items()}
+    te = {k: ([np.float32(x) for x in v] if k == "score_means" else v.tolist()) for k, v in small.items()}
+    t0 = time.perf_counter()
+    segmentation.glue_orphans(te, 100, 10)
+    segmentation.combine_adjacent(te)
+    dt_oracle = time.perf_counter() - t0
+    got = pipeline.glue_and_merge(small, 100, 10)
+    for k in ("end_frames", "frame_types", "run_lengths", "start_frames"):
+        assert got[k].tolist() == te[k], k
+    assert got["score_means"].tobytes() == np.array(te["score_means"], dtype=np.float32).tobytes()
+    print(f"glue: 100k segments {dt*1e3:.0f} ms; oracle on 2k segments {dt_oracle*1e3:.0f} ms")
+
+
+# ----------------------------------------------------------------------------- model files
+def test_reference_model_files_pack_to_the_bundled_blob(golden_dir, tmp_path):
+    """load_and_glue_nets on the reference's own three files (tests/golden/ref_prod_net, copied by
+    make_golden.py) yields exactly the bundled weights; save_reference_files writes files that load
+    back to the same blob, with the tensor names the reference's modules expect."""
+    import torch
+    from cutdet import api
+    from frameID.net import load_and_glue_nets, load_default_net
+    d = os.path.join(golden_dir, "ref_prod_net")
+    net, params = load_and_glue_nets(os.path.join(d, "init_model_model_params.json"),
+                                     os.path.join(d, "init_model_classifier_conv.pt"),
+                                     os.path.join(d, "init_model_classifier_linear.pt"))
+    assert net._blob == api.default_blob()
+    assert params["conv_layers"] == 3 and params["linear_size"] == 32
+    files = [str(tmp_path / n) for n in ("p.json", "conv.pt", "lin.pt")]
+    net.save_reference_files(*files)
+    again, params2 = load_and_glue_nets(*files)
+    assert again._blob == net._blob and params2 == params
+    ref_conv = torch.load(os.path.join(d, "init_model_classifier_conv.pt"), map_location="cpu", weights_only=True)
+    ref_lin = torch.load(os.path.join(d, "init_model_classifier_linear.pt"), map_location="cpu", weights_only=True)
+    conv, lin = load_default_net()[0].state_dicts()
+    assert list(conv) == list(ref_conv) and list(lin) == list(ref_lin)          # same names, same order
+    for k in ref_conv:
+        if ref_conv[k].dtype.is_floating_point:
+            assert torch.equal(conv[k], ref_conv[k]), k
+
+
+def test_eval_oracle_counts():
+    from oracle import evaluate
+    logits = np.array([[3, 1, 0], [0, 2, 1], [0, 1, 5], [2, 2, 0], [0, 0, 0]], np.float32)
+    labels = np.array([0, 1, 1, 1, 2])
+    r = evaluate.validate([logits[:3], logits[3:]], [labels[:3], labels[3:]])
+    assert r["correct"] == [1, 1, 0] and r["total"] == [1, 3, 1] and r["frames"] == 5
+    assert abs(r["loss"] - float(np.mean([-np.log(np.exp(l[y]) / np.exp(l).sum()) for l, y in zip(logits.astype(np.float64), labels)]))) < 1e-12

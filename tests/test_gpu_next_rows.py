@@ -1,0 +1,168 @@
+"""GPU tests of the rows next to the hot path: model files and training-side validation, the CSV
+wire format through the CLI, and scale cases of the run-length pass.  Needs an MI355X."""
+import csv
+import importlib.util
+import io
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SEED = 1234
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from cutdet import api
+    return api.default_engine("cuda:0")
+
+
+def _cli():
+    spec = importlib.util.spec_from_file_location("cd_segment_video",
+                                                  os.path.join(ROOT, "cut-detection_amd", "segment_video.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _write_clip(tmp_path, name, runs, h, w, first_index=0):
+    from cutdet import rawvideo, synth as csynth
+    from oracle import synth
+    cl = csynth.classes_from_runs(runs)
+    frames = synth.clip(SEED, cl, h, w, first_index=first_index)
+    p = str(tmp_path / name)
+    rawvideo.write_raw_video(p, frames, fps=30)
+    return p, frames, cl
+
+
+# ----------------------------------------------------------------------------- model files
+@pytest.mark.parametrize("case", ["720p", "180p"])
+def test_load_and_glue_nets_on_the_reference_files_gives_golden_logits(golden_dir, case):
+    """frameID/net.py:193-217 on the reference's own three files, then the GPU forward, against
+    logits the reference itself produced (net_golden.npz)."""
+    from frameID.net import load_and_glue_nets
+    from oracle import synth
+    d = os.path.join(golden_dir, "ref_prod_net")
+    net, params = load_and_glue_nets(os.path.join(d, "init_model_model_params.json"),
+                                     os.path.join(d, "init_model_classifier_conv.pt"),
+                                     os.path.join(d, "init_model_classifier_linear.pt"))
+    net.eval()
+    net.to("cuda:0")
+    g = np.load(os.path.join(golden_dir, "net_golden.npz"))
+    with open(os.path.join(golden_dir, "net_golden_meta.json")) as f:
+        m = json.load(f)[case]
+    frames = torch.from_numpy(synth.clip(SEED, m["classes"], m["height"], m["width"])).to("cuda:0")
+    logits, _, am = net.classify_frames(frames)
+    assert np.abs(logits.cpu().numpy() - g[f"logits_{case}"]).max() <= 1e-3
+    assert am.cpu().tolist() == m["classes"]
+    # the float entry the reference's driver uses: net(batch)
+    y = net(net.engine.preprocess(frames)).cpu().numpy()
+    assert y.tobytes() == logits.cpu().numpy().tobytes()
+
+
+def test_evaluate_matches_the_validation_loop(engine):
+    """ProdNet.evaluate against the oracle's restatement of supervised_training.py:177-215 on
+    synthetic frames with a few deliberately wrong labels: counts exact, mean loss to 1e-5."""
+    from frameID.net import load_default_net
+    from oracle import evaluate, net as onet, preprocess, synth
+    net, _ = load_default_net()
+    net.eval().to(engine.device)
+    cl = [0] * 20 + [1] * 17 + [2] * 11 + [1] * 9 + [0] * 13           # 70 frames
+    labels = np.array(cl)
+    labels[[3, 25, 40, 69]] = [1, 2, 0, 2]                              # mislabelled frames
+    frames = synth.clip(SEED, cl, 180, 320)
+    w = onet.load_blob()
+    bounds = [(0, 32), (32, 64), (64, 70)]
+    want = evaluate.validate([onet.forward(w, preprocess.preprocess_batch(frames[a:b])).numpy() for a, b in bounds],
+                             [labels[a:b] for a, b in bounds])
+    dev_frames = torch.from_numpy(frames).to(engine.device)
+    # u8 frames as (x, y) pairs with [B,1] labels (the reference's loader shape, squeezed by the script)
+    got = net.evaluate((dev_frames[a:b], torch.from_numpy(labels[a:b]).reshape(-1, 1)) for a, b in bounds)
+    assert got["correct"] == want["correct"] and got["total"] == want["total"] and got["frames"] == 70
+    assert got["correct"] == [31, 25, 10] and got["total"] == [32, 26, 12]
+    assert abs(got["loss"] - want["loss"]) <= 1e-5
+    assert got["accuracy"] == pytest.approx(want["accuracy"])
+    # float frames as the reference loader's dicts give the same counts
+    x = engine.preprocess(dev_frames)
+    got2 = net.evaluate({"x": x[a:b], "y": torch.from_numpy(labels[a:b])} for a, b in bounds)
+    assert got2["correct"] == got["correct"] and abs(got2["loss"] - got["loss"]) <= 1e-9
+    # labels outside the class range are skipped
+    bad = torch.tensor([0, 7, -1, 2])
+    got3 = net.evaluate([(dev_frames[[0, 1, 2, 40]], bad)])
+    assert got3["total"] == [1, 0, 1] and got3["frames"] == 2
+
+
+# ----------------------------------------------------------------------------- wire format through the CLI
+def test_cli_columns_and_multi_clip_stream(engine, tmp_path):
+    from oracle import net as onet, preprocess, segmentation
+    mod = _cli()
+    w = onet.load_blob()
+    clips = [("a.cdraw", [(0, 130), (2, 15), (1, 140)], 0), ("b.cdraw", [(1, 150), (2, 5), (1, 60), (0, 120)], 500)]
+    paths, want = [], {}
+    for name, runs, first in clips:
+        p, frames, cl = _write_clip(tmp_path, name, runs, 180, 320, first)
+        paths.append(p)
+        scores = np.concatenate([onet.forward(w, preprocess.preprocess_batch(frames[a:a + 100])).numpy()
+                                 for a in range(0, len(cl), 100)])
+        want[name] = segmentation.segment_clip(scores)
+    # one clip, extra columns: the first two fields of every row are the reference's CSV
+    out = mod.main(mod.sv_parser.parse_args([paths[0], "--output_path", str(tmp_path / "wide.csv"), "--columns",
+                                             "start,type,end_frame,run_length,score_mean", "--batch-size", "64"]))
+    rows = list(csv.reader(io.StringIO(open(out, newline="").read(), newline="")))
+    merged = want["a.cdraw"][2]
+    assert ("\r\n".join(",".join(r[:2]) for r in rows) + "\r\n").encode() == want["a.cdraw"][3]
+    assert [int(r[2]) for r in rows] == merged["end_frames"] and [int(r[3]) for r in rows] == merged["run_lengths"]
+    np.testing.assert_allclose([float(r[4]) for r in rows], np.array(merged["score_means"], dtype=np.float64), rtol=2e-6)
+    # default columns: byte-identical to the reference's writer
+    out = mod.main(mod.sv_parser.parse_args([paths[0], "--output_path", str(tmp_path / "plain.csv")]))
+    assert open(out, "rb").read() == want["a.cdraw"][3]
+    # two clips: one streamed file with a clip column
+    out = mod.main(mod.sv_parser.parse_args([paths[0], "--more-inputs", paths[1], "--output_path",
+                                             str(tmp_path / "both.csv"), "--batch-size", "64"]))
+    data = open(out, "rb").read()
+    expect = b"".join(b"".join(name.encode() + b"," + line + b"\r\n" for line in want[name][3].split(b"\r\n") if line)
+                      for name, _, _ in clips)
+    assert data == expect
+
+
+def test_cli_keep_lone_orphan(engine, tmp_path):
+    mod = _cli()
+    p, _, _ = _write_clip(tmp_path, "short.cdraw", [(0, 75)], 180, 320)       # one shot, shorter than 100 frames
+    with pytest.raises(IndexError):
+        mod.main(mod.sv_parser.parse_args([p]))
+    out = mod.main(mod.sv_parser.parse_args([p, "--keep-lone-orphan", "--columns", "start,type,end_frame"]))
+    rows = open(out, "rb").read().split(b"\r\n")
+    assert len(rows) == 2 and rows[0].split(b",")[0] == b"0" and rows[0].split(b",")[2] == b"74"
+
+
+# ----------------------------------------------------------------------------- run-length scale cases
+def test_rle_one_16m_frame_segment(engine):
+    """A single segment of 2^24 frames (one wavefront sums it): exact table, mean within fp32
+    rounding of the fp64 mean, in bounded time."""
+    n = 1 << 24
+    dev = engine.device
+    cls = torch.ones((n,), dtype=torch.int64, device=dev)
+    mx = torch.rand((n,), dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 8 + 1
+    engine.rle(cls[:4096], mx[:4096])                       # warm the kernels
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    te = engine.rle(cls, mx, frame_offset=5)
+    dt = time.perf_counter() - t0
+    assert te["end_frames"].cpu().tolist() == [n - 1 + 5] and te["start_frames"].cpu().tolist() == [5]
+    assert te["run_lengths"].cpu().tolist() == [n] and te["frame_types"].cpu().tolist() == [1]
+    want = mx.double().sum().item()
+    assert abs(te["score_sums"].item() - want) <= 1e-9 * want
+    assert te["score_means"].item() == np.float32(want / n)
+    assert dt < 2.0, f"{dt:.3f} s"
+    print(f"rle of one 2^24-frame segment: {dt*1e3:.1f} ms")
+    # two long segments with a single-frame one between them
+    cls[n // 2] = 2
+    te = engine.rle(cls, mx)
+    assert te["run_lengths"].cpu().tolist() == [n // 2, 1, n - n // 2 - 1]
+    assert te["score_means"][1].item() == mx[n // 2].item()
