@@ -76,5 +76,19 @@ class RawVideoCapture:
             return np.array(self._frames[a:b])
         return np.ascontiguousarray(self._frames[a:b][:, np.asarray(rows, dtype=np.int64)])
 
+    def read_batch_into(self, out, rows=None, copier=None):
+        """read_batch() into a caller-owned array (e.g. page-locked memory): fills out[:k] and returns
+        k (0 at the end).  `copier`: a cutdet.ingest.ParallelCopier to spread the copy over threads."""
+        a, b = self._pos, min(self.length, self._pos + out.shape[0])
+        self._pos = b
+        if b > a:
+            if copier is not None:
+                copier.copy(self._frames[a:b], out, rows)
+            elif rows is None:
+                np.copyto(out[:b - a], self._frames[a:b])
+            else:
+                np.take(self._frames[a:b], np.asarray(rows, dtype=np.intp), axis=1, out=out[:b - a])
+        return b - a
+
     def release(self):
         self._frames = None

@@ -12,7 +12,9 @@ they define (reference :116) is kept because the segmentation output needs it.
 import torch
 from torch.utils.data import IterableDataset
 
-from cutdet import api, rawvideo
+import numpy as np
+
+from cutdet import api, ingest, rawvideo
 from cutdet.engine import sampled_source_rows
 
 
@@ -60,45 +62,65 @@ class VideoDataset(IterableDataset):
             self.new_height = None
         self._ready = None   # preprocessed frames of the current read-ahead batch
         self._next = 0
-        # Rows the resize actually reads, when the container can hand over rows and the vertical pass
-        # is a point sample (720p: 144 of 720 rows): frame_batches() then uploads only those, which
-        # is what bounds real clips (2.76 MB per 720p frame over PCIe), and `batch_net_height` tells
-        # the classifier that the rows are already the network's.
+        # Rows the resize actually reads when its vertical pass is a point sample (720p: 144 of 720
+        # rows): frame_batches() then uploads only those, which is what bounds real clips (2.76 MB per
+        # 720p frame over PCIe), and `batch_net_height` tells the classifier that the rows are already
+        # the network's.  The raw container never reads the other rows from the file; frames decoded
+        # by OpenCV are cut down on the host before the upload.
         self.sampled_rows = None
-        if resize is not None and hasattr(self.cap, "read_batch"):
+        if resize is not None:
             self.sampled_rows = sampled_source_rows(self.video_info["height"], self.video_info["width"], resize)
         self.batch_net_height = self.new_height if self.sampled_rows is not None else None
+        self._copier = None
+        self._ended = False
 
     # --- decoded frames ------------------------------------------------------------------
+    def _fill(self, out, rows):
+        """Next decoded frames (only `rows` of each, if given) into out[:k]; returns k."""
+        if hasattr(self.cap, "read_batch_into"):
+            if self._copier is None:
+                self._copier = ingest.ParallelCopier()
+            return self.cap.read_batch_into(out, rows, self._copier)
+        idx = None if rows is None else np.asarray(rows, dtype=np.intp)
+        k = 0
+        while k < out.shape[0] and not self._ended:
+            ret, frame = self.cap.read()          # reference frameID/data.py:213
+            if not ret:
+                self._ended = True                # like the reference's iterator, stop at the first failed read
+                break
+            if idx is None:
+                np.copyto(out[k], frame)
+            else:
+                np.take(frame, idx, axis=0, out=out[k])
+            k += 1
+        return k
+
     def read_u8_batch(self, n, rows=None):
         """Next up-to-n decoded frames as a u8 [k,H,W,3] tensor on the GPU (k = 0 at the end);
-        `rows` (raw container only) restricts every frame to those rows."""
-        if hasattr(self.cap, "read_batch"):
-            arr = self.cap.read_batch(n, rows) if rows is not None else self.cap.read_batch(n)
-            host = torch.from_numpy(arr)
-        else:
-            got = []
-            while len(got) < n:
-                ret, frame = self.cap.read()
-                if not ret:
-                    break
-                got.append(torch.from_numpy(frame))
-            host = torch.stack(got) if got else torch.empty((0, self.video_info["height"],
-                                                             self.video_info["width"], 3), dtype=torch.uint8)
-        return host.to(self.device, non_blocking=False)
+        `rows` restricts every frame to those rows.  Synchronous; frame_batches() overlaps."""
+        h = self.video_info["height"] if rows is None else len(rows)
+        host = np.empty((n, h, self.video_info["width"], 3), dtype=np.uint8)
+        k = self._fill(host, rows)
+        return torch.from_numpy(host[:k]).to(self.device, non_blocking=False)
 
-    def frame_batches(self, batch_size, sampled=True):
+    def frame_batches(self, batch_size, sampled=True, overlap=True):
         """Yields u8 GPU batches for the fused classify path (no float frames materialised).  With
         `sampled` and a point-sampling geometry the batches hold only the sampled rows
-        ([k, new_height, W, 3]); classify them with net_h=self.batch_net_height."""
+        ([k, new_height, W, 3]); classify them with net_h=self.batch_net_height.
+        With `overlap` (default) batches come through a page-locked double buffer and a copy stream:
+        batch i+1 is read and uploaded while the GPU classifies batch i, and a yielded batch is valid
+        only until the next one is requested."""
         rows = self.sampled_rows if sampled else None
-        if rows is None:
-            self.batch_net_height = None
-        while True:
-            b = self.read_u8_batch(batch_size, rows)
-            if b.shape[0] == 0:
-                return
-            yield b
+        self.batch_net_height = self.new_height if rows is not None else None
+        if not overlap:
+            while True:
+                b = self.read_u8_batch(batch_size, rows)
+                if b.shape[0] == 0:
+                    return
+                yield b
+        h = self.video_info["height"] if rows is None else len(rows)
+        up = ingest.BatchUploader(self.device, batch_size, (h, self.video_info["width"], 3))
+        yield from up.batches(lambda out: self._fill(out, rows))
 
     # --- the reference's iteration protocol ---------------------------------------------------
     def __iter__(self):

@@ -359,3 +359,21 @@ def test_eval_oracle_counts():
     r = evaluate.validate([logits[:3], logits[3:]], [labels[:3], labels[3:]])
     assert r["correct"] == [1, 1, 0] and r["total"] == [1, 3, 1] and r["frames"] == 5
     assert abs(r["loss"] - float(np.mean([-np.log(np.exp(l[y]) / np.exp(l).sum()) for l, y in zip(logits.astype(np.float64), labels)]))) < 1e-12
+
+
+# ----------------------------------------------------------------------------- ingest (host side)
+def test_parallel_copier_and_read_batch_into(tmp_path):
+    from cutdet import ingest, rawvideo
+    rs = np.random.RandomState(0)
+    frames = rs.randint(0, 256, size=(37, 20, 12, 3)).astype(np.uint8)
+    p = str(tmp_path / "c.cdraw")
+    rawvideo.write_raw_video(p, frames)
+    rows = [1, 4, 7, 19]
+    for copier in (None, ingest.ParallelCopier(4), ingest.ParallelCopier(1)):
+        cap = rawvideo.RawVideoCapture(p)
+        out = np.zeros((16, 20, 12, 3), np.uint8)
+        assert cap.read_batch_into(out, None, copier) == 16 and (out == frames[:16]).all()
+        cut = np.zeros((16, 4, 12, 3), np.uint8)
+        assert cap.read_batch_into(cut, rows, copier) == 16 and (cut == frames[16:32][:, rows]).all()
+        assert cap.read_batch_into(cut, rows, copier) == 5 and (cut[:5] == frames[32:][:, rows]).all()
+        assert cap.read_batch_into(cut, rows, copier) == 0

@@ -263,29 +263,69 @@ def test_segment_video_cli_1k_frames_320x180(engine, oracle_weights, tmp_path):
         mod.main(mod.sv_parser.parse_args([path, "--cpu"]))
 
 
-def test_sampled_row_ingest_is_bit_identical(engine, tmp_path):
+def test_sampled_row_ingest_is_bit_identical(engine, oracle_weights, tmp_path):
     """720p clip from the raw container: uploading only the 144 sampled rows of each frame and
-    classifying them with net_h=144 must give the same logits, bit for bit, as the full frames."""
+    classifying them with net_h=144 must give the same logits, bit for bit, as the full frames -
+    through the overlapped (pinned double buffer + copy stream) path and the synchronous one - and
+    those logits must be the oracle's."""
     from frameID.data import VideoDataset
     from frameID.net import load_default_net
+    from oracle import net as onet
+    from oracle import preprocess
     runs = [(0, 20), (1, 25), (2, 19)]
     path, frames, cl = _write_clip(tmp_path, runs, 720, 1280)
+    want = np.concatenate([onet.forward(oracle_weights, preprocess.preprocess_batch(frames[a:a + 16])).numpy()
+                           for a in range(0, len(cl), 16)])
     net, _ = load_default_net()
     net.eval().to(engine.device)
     full = VideoDataset(path, resize=256, device=engine.device)
     a = torch.cat([net.classify_frames(b, chan_order=full.chan_order)[0] for b in full.frame_batches(32, sampled=False)])
-    ds = VideoDataset(path, resize=256, device=engine.device)
-    assert ds.sampled_rows == [5 * y + 2 for y in range(144)]
-    got = []
-    for b in ds.frame_batches(32):
-        assert tuple(b.shape[1:]) == (144, 1280, 3) and ds.batch_net_height == 144
-        got.append(net.classify_frames(b, chan_order=ds.chan_order, net_h=ds.batch_net_height))
-    assert torch.equal(a, torch.cat([g[0] for g in got]))
-    assert torch.cat([g[2] for g in got]).cpu().tolist() == cl
+    assert np.abs(a.cpu().numpy() - want).max() <= LOGIT_TOL
+    for overlap in (True, False):
+        ds = VideoDataset(path, resize=256, device=engine.device)
+        assert ds.sampled_rows == [5 * y + 2 for y in range(144)]
+        got = []
+        for b in ds.frame_batches(24, overlap=overlap):          # 64 frames: 24 + 24 + 16, three buffer reuses
+            assert tuple(b.shape[1:]) == (144, 1280, 3) and ds.batch_net_height == 144
+            got.append(net.classify_frames(b, chan_order=ds.chan_order, net_h=ds.batch_net_height))
+        assert torch.equal(a, torch.cat([g[0] for g in got]))
+        assert torch.cat([g[2] for g in got]).cpu().tolist() == cl
     # a geometry that is not a point sample keeps whole frames
     p2, _, _ = _write_clip(tmp_path, [(0, 3)], 180, 320)
     d2 = VideoDataset(p2, resize=256, device=engine.device)
     assert d2.sampled_rows is None and next(iter(d2.frame_batches(8))).shape[1] == 180 and d2.batch_net_height is None
+
+
+class _ReadOnlyCapture:
+    """What cv2.VideoCapture offers the dataset: read() one BGR frame at a time, nothing else."""
+
+    def __init__(self, path):
+        from cutdet import rawvideo
+        self._cap = rawvideo.RawVideoCapture(path)
+        self.reads = 0
+
+    def read(self):
+        self.reads += 1
+        return self._cap.read()
+
+
+def test_frames_decoded_one_by_one_are_cut_to_sampled_rows_before_upload(engine, tmp_path):
+    """The cv2 route (reference frameID/data.py:211-216): frames arrive one at a time from read();
+    only their sampled rows are staged and uploaded, and the logits equal the whole-frame ones."""
+    from frameID.data import VideoDataset
+    from frameID.net import load_default_net
+    path, frames, cl = _write_clip(tmp_path, [(1, 9), (0, 10)], 720, 1280)
+    net, _ = load_default_net()
+    net.eval().to(engine.device)
+    want = net.classify_frames(torch.from_numpy(frames).to(engine.device))[0]
+    ds = VideoDataset(path, resize=256, device=engine.device)
+    ds.cap = _ReadOnlyCapture(path)                               # no read_batch / read_batch_into
+    got = []
+    for b in ds.frame_batches(8):
+        assert tuple(b.shape[1:]) == (144, 1280, 3)
+        got.append(net.classify_frames(b, chan_order=0, net_h=ds.batch_net_height)[0])
+    assert torch.equal(torch.cat(got), want)
+    assert ds.cap.reads == len(cl) + 1                            # every frame once, plus the end-of-stream read
 
 
 def test_reference_style_driver_loop(engine, oracle_weights, tmp_path):
