@@ -131,6 +131,9 @@ int launch_rle(const cd_handle* h, const int64_t* cls, const float* maxv, int64_
                int64_t* end, int64_t* type, int64_t* runlen, int64_t* start, float* mean, double* sum,
                int64_t cap, int64_t* n_seg, hipStream_t s);
 int launch_max_argmax(const float* scores, int64_t n, int ncls, float* maxv, int64_t* argmax, hipStream_t s);
+int launch_nv12_to_bgr(const uint8_t* y, const uint8_t* uv, int n, int W0, int64_t y_rs, int64_t uv_rs,
+                       int64_t y_fs, int64_t uv_fs, const int32_t* y_rows, const int32_t* uv_rows, int n_rows,
+                       uint8_t* dst, int chan_order, hipStream_t s);
 int launch_eval_accumulate(const float* logits, const int64_t* labels, int64_t n, int ncls, int64_t* correct,
                            int64_t* total, double* loss_sum, hipStream_t s);
 int launch_synth(uint8_t* dst, int n, int H0, int W0, const uint8_t* classes, uint32_t seed,

@@ -445,6 +445,24 @@ int cd_preprocess(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64
     return launch_preprocess(h, src, n, H0, W0, row_stride, frame_stride, chan_order, dst, net_h, net_w, s);
 }
 
+int cd_nv12_to_bgr(cd_handle* h, const uint8_t* y, const uint8_t* uv, int n, int W0, int64_t y_row_stride,
+                   int64_t uv_row_stride, int64_t y_frame_stride, int64_t uv_frame_stride, const int32_t* y_rows,
+                   const int32_t* uv_rows, int n_rows, uint8_t* dst, int chan_order, void* stream) {
+    if (!h || !y || !uv || !dst || n < 1 || n > 65535 || n_rows < 1 || n_rows > 65535 || W0 < 2 || (W0 & 1)) {
+        set_error("cd_nv12_to_bgr: null argument, empty batch, more than 65535 frames or rows, or an odd width");
+        return CD_EINVAL;
+    }
+    if (chan_order != CD_BGR && chan_order != CD_RGB) { set_error("cd_nv12_to_bgr: chan_order %d", chan_order); return CD_EINVAL; }
+    if (y_row_stride < W0 || uv_row_stride < W0) {
+        set_error("cd_nv12_to_bgr: row strides (%lld, %lld) smaller than the %d-byte rows", (long long)y_row_stride,
+                  (long long)uv_row_stride, W0);
+        return CD_EINVAL;
+    }
+    DeviceGuard guard(h->device);
+    return launch_nv12_to_bgr(y, uv, n, W0, y_row_stride, uv_row_stride, y_frame_stride, uv_frame_stride, y_rows,
+                              uv_rows, n_rows, dst, chan_order, static_cast<hipStream_t>(stream));
+}
+
 int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w, float* logits, float* maxv,
                int64_t* argmax, void* stream) {
     if (!h || !x || !logits) { set_error("cd_forward: null argument"); return CD_EINVAL; }

@@ -111,6 +111,76 @@ int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int
 }
 
 // ------------------------------------------------------------------------------------------
+// NV12 -> interleaved BGR/RGB u8, optionally only selected rows (HBM-bound: 1.5 bytes in, 3 out per
+// pixel).  Arithmetic: ITU-R BT.601 limited range with 20-bit coefficients, as OpenCV's
+// cvtColor(COLOR_YUV2BGR_NV12) publishes it - the conversion cv2.VideoCapture.read() has already
+// applied to the frames the reference sees (frameID/data.py:213).
+// One thread converts 4 pixels: one dword of luma, one dword of chroma (two U,V pairs), three
+// dwords out, so a wave reads 256 + 256 contiguous bytes and writes 768.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sat8(int v) { return (uint32_t)min(max(v, 0), 255); }
+
+__device__ __forceinline__ uint32_t nv12_pixel(int Y, int U, int V, bool bgr) {
+    const int y = max(0, Y - 16) * 1220542 + (1 << 19);
+    const uint32_t r = sat8((y + 1673527 * V) >> 20);
+    const uint32_t g = sat8((y - 852492 * V - 409993 * U) >> 20);
+    const uint32_t b = sat8((y + 2116026 * U) >> 20);
+    return bgr ? (b | (g << 8) | (r << 16)) : (r | (g << 8) | (b << 16));
+}
+
+__global__ __launch_bounds__(256) void nv12_to_bgr_kernel(
+    const uint8_t* __restrict__ yp, const uint8_t* __restrict__ uvp, int W0, int64_t y_rs, int64_t uv_rs,
+    int64_t y_fs, int64_t uv_fs, const int32_t* __restrict__ y_rows, const int32_t* __restrict__ uv_rows,
+    int n_rows, uint8_t* __restrict__ dst, int chan_order, int quads, bool aligned) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y, f = blockIdx.z;
+    if (q >= quads) return;
+    const int yr = y_rows ? y_rows[r] : r, ur = uv_rows ? uv_rows[r] : (yr >> 1);
+    const uint8_t* ys = yp + (int64_t)f * y_fs + (int64_t)yr * y_rs + 4 * q;
+    const uint8_t* us = uvp + (int64_t)f * uv_fs + (int64_t)ur * uv_rs + 4 * q;
+    uint8_t* out = dst + (((int64_t)f * n_rows + r) * W0 + 4 * q) * 3;
+    const bool bgr = chan_order == CD_BGR;
+    const int left = W0 - 4 * q;                 // pixels this thread owns (4, or fewer at the row end)
+    uint32_t y4 = 0, uv4 = 0;
+    if (aligned && left >= 4) {
+        y4 = *reinterpret_cast<const uint32_t*>(ys);
+        uv4 = *reinterpret_cast<const uint32_t*>(us);
+    } else {
+        for (int k = 0; k < min(left, 4); ++k) y4 |= (uint32_t)ys[k] << (8 * k);
+        for (int k = 0; k < min((left + 1) & ~1, 4); ++k) uv4 |= (uint32_t)us[k] << (8 * k);
+    }
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int U = (int)((uv4 >> (16 * (k >> 1))) & 255) - 128, V = (int)((uv4 >> (16 * (k >> 1) + 8)) & 255) - 128;
+        px[k] = nv12_pixel((int)((y4 >> (8 * k)) & 255), U, V, bgr);
+    }
+    if (aligned && left >= 4) {
+        uint32_t* o = reinterpret_cast<uint32_t*>(out);
+        o[0] = px[0] | (px[1] << 24);
+        o[1] = (px[1] >> 8) | (px[2] << 16);
+        o[2] = (px[2] >> 16) | (px[3] << 8);
+    } else {
+        for (int k = 0; k < min(left, 4); ++k)
+            for (int c = 0; c < 3; ++c) out[3 * k + c] = (uint8_t)(px[k] >> (8 * c));
+    }
+}
+
+int launch_nv12_to_bgr(const uint8_t* y, const uint8_t* uv, int n, int W0, int64_t y_rs, int64_t uv_rs,
+                       int64_t y_fs, int64_t uv_fs, const int32_t* y_rows, const int32_t* uv_rows, int n_rows,
+                       uint8_t* dst, int chan_order, hipStream_t s) {
+    const int quads = (W0 + 3) / 4;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(uv) |
+                           reinterpret_cast<uintptr_t>(dst) | (uintptr_t)y_rs | (uintptr_t)uv_rs | (uintptr_t)y_fs |
+                           (uintptr_t)uv_fs | (uintptr_t)W0;
+    dim3 grid((unsigned)((quads + 255) / 256), (unsigned)n_rows, (unsigned)n), block(256);
+    hipLaunchKernelGGL(nv12_to_bgr_kernel, grid, block, 0, s, y, uv, W0, y_rs, uv_rs, y_fs, uv_fs, y_rows, uv_rows,
+                       n_rows, dst, chan_order, quads, (bits & 3) == 0);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Synthetic clip generator: integer hash, four bytes per thread.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -96,6 +96,36 @@ class Engine:
                                 self._stream()))
         return out
 
+    def nv12_to_bgr(self, y, uv, y_rows=None, uv_rows=None, chan_order=_lib.CD_BGR, out=None):
+        """NV12 planes on the GPU - y u8 [n, Hy, W], uv u8 [n, Huv, W] (views with padded rows are
+        fine) - to interleaved pixels u8 [n, rows, W, 3].  Output row r uses luma row y_rows[r] and
+        chroma row uv_rows[r] (int32 device tensors; default: every luma row and row r // 2)."""
+        self._check_dev(y, "y", torch.uint8)
+        self._check_dev(uv, "uv", torch.uint8)
+        if y.dim() != 3 or uv.dim() != 3 or y.shape[0] != uv.shape[0] or y.shape[2] != uv.shape[2] or \
+                y.stride(2) != 1 or uv.stride(2) != 1:
+            raise ValueError("y and uv must be u8 [n, rows, W] with contiguous rows")
+        n, hy, w = y.shape
+        for name, t in (("y_rows", y_rows), ("uv_rows", uv_rows)):
+            if t is not None:
+                self._check_dev(t, name, torch.int32)
+        if (y_rows is None) != (uv_rows is None) and y_rows is None:
+            raise ValueError("uv_rows without y_rows")
+        n_rows = hy if y_rows is None else int(y_rows.shape[0])
+        if uv_rows is not None and uv_rows.shape[0] != n_rows:
+            raise ValueError("y_rows and uv_rows differ in length")
+        if y_rows is None and uv.shape[1] * 2 < hy:
+            raise ValueError("uv plane too short for the luma plane")
+        if out is None:
+            out = torch.empty((n, n_rows, w, 3), dtype=torch.uint8, device=self.device)
+        fs = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.stride(1) * t.shape[1])  # noqa: E731
+        if n:
+            check(lib.cd_nv12_to_bgr(self._h, _ptr(y), _ptr(uv), n, w, y.stride(1), uv.stride(1), fs(y), fs(uv),
+                                     _ptr(y_rows.contiguous() if y_rows is not None else None),
+                                     _ptr(uv_rows.contiguous() if uv_rows is not None else None), n_rows, _ptr(out),
+                                     chan_order, self._stream()))
+        return out
+
     def _outputs(self, n, want_max, out=None):
         if out is not None:
             logits, mx, am = out

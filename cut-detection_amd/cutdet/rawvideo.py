@@ -4,9 +4,11 @@ Video decoding is outside this package (the reference delegates it to OpenCV,
 frameID/data.py:19-24,213); boxes without OpenCV can still feed the pipeline from this format.
 
     offset  0  8 bytes  magic b"CDRAWVID"
-            8  u32 x 6  version (1), width, height, frame count, fps, channel order (0 BGR, 1 RGB)
+            8  u32 x 6  version (1), width, height, frame count, fps, pixel format
+                        (0 BGR, 1 RGB: interleaved 3-byte pixels; 2 NV12: a height x width luma plane
+                        followed by a height/2 x width plane of interleaved U,V pairs)
            32  zero padding to 64 bytes
-           64  frames, each height*width*3 bytes, rows top to bottom, pixels interleaved
+           64  frames, rows top to bottom: height*width*3 bytes each (BGR/RGB) or height*width*3/2 (NV12)
 """
 import struct
 
@@ -19,12 +21,21 @@ HEADER_BYTES = 64
 CAP_PROP_FRAME_WIDTH, CAP_PROP_FRAME_HEIGHT, CAP_PROP_FPS, CAP_PROP_FRAME_COUNT = 3, 4, 5, 7
 
 
+NV12 = 2
+
+
 def write_raw_video(path, frames, fps=30, chan_order=0):
-    """frames: u8 array [n, H, W, 3] (or an iterable of [H, W, 3] arrays)."""
+    """frames: u8 array [n, H, W, 3] (or an iterable of [H, W, 3] arrays); with chan_order=NV12,
+    [n, H*3/2, W]: every frame its luma rows followed by its chroma rows."""
     frames = np.asarray(frames, dtype=np.uint8)
-    if frames.ndim != 4 or frames.shape[3] != 3:
+    if chan_order == NV12:
+        if frames.ndim != 3 or frames.shape[1] % 3 or frames.shape[2] % 2:
+            raise ValueError("NV12 frames must be [n, H*3/2, W] uint8 with even H and W")
+        n, h, w = frames.shape[0], frames.shape[1] * 2 // 3, frames.shape[2]
+    elif frames.ndim != 4 or frames.shape[3] != 3:
         raise ValueError("frames must be [n, H, W, 3] uint8")
-    n, h, w, _ = frames.shape
+    else:
+        n, h, w, _ = frames.shape
     with open(path, "wb") as f:
         f.write(MAGIC + struct.pack("<6I", 1, w, h, n, int(fps), int(chan_order)) + b"\0" * (HEADER_BYTES - 32))
         f.write(np.ascontiguousarray(frames).tobytes())
@@ -49,8 +60,9 @@ class RawVideoCapture:
         ver, self.width, self.height, self.length, self.fps, self.chan_order = struct.unpack("<6I", head[8:32])
         if ver != 1:
             raise ValueError(f"{path}: unsupported CDRAWVID version {ver}")
-        self._frames = np.memmap(path, dtype=np.uint8, mode="r", offset=HEADER_BYTES,
-                                 shape=(self.length, self.height, self.width, 3))
+        self.nv12 = self.chan_order == NV12
+        shape = (self.length, self.height * 3 // 2, self.width) if self.nv12 else (self.length, self.height, self.width, 3)
+        self._frames = np.memmap(path, dtype=np.uint8, mode="r", offset=HEADER_BYTES, shape=shape)
         self._pos = 0
 
     def isOpened(self):

@@ -61,6 +61,7 @@ class VideoDataset(IterableDataset):
             self.new_width = None
             self.new_height = None
         self._ready = None   # preprocessed frames of the current read-ahead batch
+        self._nv12_iter = None
         self._next = 0
         # Rows the resize actually reads when its vertical pass is a point sample (720p: 144 of 720
         # rows): frame_batches() then uploads only those, which is what bounds real clips (2.76 MB per
@@ -73,6 +74,12 @@ class VideoDataset(IterableDataset):
         self.batch_net_height = self.new_height if self.sampled_rows is not None else None
         self._copier = None
         self._ended = False
+        # NV12 containers (what hardware decoders deliver) are uploaded as planes - half the bytes of
+        # BGR - and converted on the GPU; sampled-row upload takes the luma rows the resize reads and
+        # the chroma row under each of them.
+        self.nv12 = bool(getattr(self.cap, "nv12", False))
+        if self.nv12:
+            self.chan_order = 0          # the converter writes BGR
 
     # --- decoded frames ------------------------------------------------------------------
     def _fill(self, out, rows):
@@ -112,6 +119,9 @@ class VideoDataset(IterableDataset):
         only until the next one is requested."""
         rows = self.sampled_rows if sampled else None
         self.batch_net_height = self.new_height if rows is not None else None
+        if self.nv12:
+            yield from self._nv12_batches(batch_size, rows, overlap)
+            return
         if not overlap:
             while True:
                 b = self.read_u8_batch(batch_size, rows)
@@ -122,13 +132,49 @@ class VideoDataset(IterableDataset):
         up = ingest.BatchUploader(self.device, batch_size, (h, self.video_info["width"], 3))
         yield from up.batches(lambda out: self._fill(out, rows))
 
+    def _nv12_batches(self, batch_size, rows, overlap):
+        """NV12 container: plane rows are uploaded ([k, R, W] u8: the luma rows, then the chroma rows)
+        and converted to BGR on the GPU (cd_nv12_to_bgr)."""
+        H, W = self.video_info["height"], self.video_info["width"]
+        eng = api.default_engine(self.device)
+        if rows is None:
+            file_rows, ny, sel = None, H, (None, None)
+        else:
+            file_rows = list(rows) + [H + r // 2 for r in rows]          # chroma row r//2 lies under luma row r
+            ny = len(rows)
+            ident = torch.arange(ny, dtype=torch.int32, device=self.device)
+            sel = (ident, ident)                                        # uploaded row r pairs with uploaded chroma row r
+        total = H * 3 // 2 if file_rows is None else len(file_rows)
+
+        def convert(planes):
+            return eng.nv12_to_bgr(planes[:, :ny], planes[:, ny:], sel[0], sel[1])
+
+        if overlap:
+            up = ingest.BatchUploader(self.device, batch_size, (total, W))
+            for planes in up.batches(lambda out: self._fill(out, file_rows)):
+                yield convert(planes)
+            return
+        while True:
+            host = np.empty((batch_size, total, W), dtype=np.uint8)
+            k = self._fill(host, file_rows)
+            if k == 0:
+                return
+            yield convert(torch.from_numpy(host[:k]).to(self.device))
+
     # --- the reference's iteration protocol ---------------------------------------------------
     def __iter__(self):
         return self
 
     def __next__(self):
         if self._ready is None or self._next >= self._ready.shape[0]:
-            raw = self.read_u8_batch(self.read_ahead)
+            if self.nv12:
+                if self._nv12_iter is None:
+                    self._nv12_iter = self._nv12_batches(self.read_ahead, None, False)
+                raw = next(self._nv12_iter, None)
+                if raw is None:
+                    raise StopIteration
+            else:
+                raw = self.read_u8_batch(self.read_ahead)
             if raw.shape[0] == 0:
                 raise StopIteration
             eng = api.default_engine(self.device)

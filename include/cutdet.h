@@ -89,6 +89,22 @@ int cd_preprocess(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
                   int64_t row_stride, int64_t frame_stride, int chan_order,
                   float* dst, int net_h, int net_w, void* stream);
 
+/* NV12 frames (what hardware video decoders deliver: a luma plane, then a half-height plane of
+ * interleaved U,V pairs, each pair shared by a 2x2 pixel block) -> interleaved 3-byte pixels, the
+ * input format of cd_preprocess / cd_forward_u8.  Stands in for the colour conversion that
+ * cv2.VideoCapture.read() has already applied to the frames the reference sees
+ * (frameID/data.py:213); BT.601 limited range in the 20-bit fixed point OpenCV's
+ * cvtColor(COLOR_YUV2BGR_NV12) publishes.  Parity unpinned: the reference never handles NV12.
+ * y: device u8, n planes of rows of y_row_stride bytes, y_frame_stride bytes apart; uv likewise.
+ * Output row r of a frame is built from luma row y_rows[r] and chroma row uv_rows[r] (device
+ * int32 [n_rows] each; NULL = row r and row y_row/2), so a caller that uploaded only the rows the
+ * resize samples converts just those.  dst: device u8 [n][n_rows][W0][3].  W0 must be even. */
+int cd_nv12_to_bgr(cd_handle* h, const uint8_t* y, const uint8_t* uv, int n, int W0,
+                   int64_t y_row_stride, int64_t uv_row_stride,
+                   int64_t y_frame_stride, int64_t uv_frame_stride,
+                   const int32_t* y_rows, const int32_t* uv_rows, int n_rows,
+                   uint8_t* dst, int chan_order, void* stream);
+
 /* prod_net forward on preprocessed frames.
  * Replaces net(batch) at segment_video.py:45 (frameID/net.py:33-40,62-68,122-133) and, through
  * maxv/argmax, torch.max(scores, 1) at frameID/segmentation.py:37.

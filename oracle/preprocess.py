@@ -97,3 +97,35 @@ def preprocess(frame_u8, resize=256, chan_order=0):
 
 def preprocess_batch(frames_u8, resize=256, chan_order=0):
     return np.stack([preprocess(f, resize, chan_order) for f in frames_u8])
+
+
+# ----------------------------------------------------------------------------------------------
+# NV12 -> BGR.  PARITY UNPINNED: the reference never sees NV12 - cv2.VideoCapture.read()
+# (frameID/data.py:213) hands it BGR, converted inside OpenCV's bundled decoder.  This restates the
+# published fixed-point arithmetic of OpenCV's cvtColor(COLOR_YUV2BGR_NV12) (imgproc color_yuv,
+# ITU-R BT.601 limited range, 20-bit coefficients): for a pixel (Y, U, V), U/V shared by a 2x2 block,
+#   y = max(0, Y - 16) * 1220542
+#   R = sat8((y + 1673527*(V-128)                  + (1 << 19)) >> 20)
+#   G = sat8((y -  852492*(V-128) - 409993*(U-128) + (1 << 19)) >> 20)
+#   B = sat8((y + 2116026*(U-128)                  + (1 << 19)) >> 20)
+NV12_CY, NV12_CVR, NV12_CVG, NV12_CUG, NV12_CUB, NV12_SHIFT = 1220542, 1673527, -852492, -409993, 2116026, 20
+
+
+def nv12_to_bgr(y_plane, uv_plane, y_rows=None, uv_rows=None, chan_order=0):
+    """y_plane u8 [Hy, W], uv_plane u8 [Huv, W] (U, V interleaved) -> u8 [rows, W, 3].
+    Output row r takes luma row y_rows[r] (default r) and chroma row uv_rows[r] (default r // 2)."""
+    y_plane, uv_plane = np.asarray(y_plane), np.asarray(uv_plane)
+    n = y_plane.shape[0] if y_rows is None else len(y_rows)
+    yr = np.arange(n) if y_rows is None else np.asarray(y_rows)
+    ur = yr // 2 if uv_rows is None else np.asarray(uv_rows)
+    Y = y_plane[yr].astype(np.int64)
+    uv = uv_plane[ur].astype(np.int64)
+    U = np.repeat(uv[:, 0::2], 2, axis=1)[:, :Y.shape[1]] - 128
+    V = np.repeat(uv[:, 1::2], 2, axis=1)[:, :Y.shape[1]] - 128
+    y = np.maximum(0, Y - 16) * NV12_CY
+    half = 1 << (NV12_SHIFT - 1)
+    r = np.clip((y + NV12_CVR * V + half) >> NV12_SHIFT, 0, 255)
+    g = np.clip((y + NV12_CVG * V + NV12_CUG * U + half) >> NV12_SHIFT, 0, 255)
+    b = np.clip((y + NV12_CUB * U + half) >> NV12_SHIFT, 0, 255)
+    out = np.stack([b, g, r] if chan_order == 0 else [r, g, b], axis=-1)
+    return out.astype(np.uint8)

@@ -377,3 +377,23 @@ def test_parallel_copier_and_read_batch_into(tmp_path):
         assert cap.read_batch_into(cut, rows, copier) == 16 and (cut == frames[16:32][:, rows]).all()
         assert cap.read_batch_into(cut, rows, copier) == 5 and (cut[:5] == frames[32:][:, rows]).all()
         assert cap.read_batch_into(cut, rows, copier) == 0
+
+
+def test_nv12_oracle_known_values_and_container(tmp_path):
+    from cutdet import rawvideo
+    from oracle import preprocess
+    y = np.array([[16, 235, 128, 81]], np.uint8)
+    uv = np.array([[128, 128, 90, 240]], np.uint8)                 # grey pair, then a saturated red-ish pair
+    bgr = preprocess.nv12_to_bgr(y, uv, y_rows=[0], uv_rows=[0])
+    assert bgr[0, 0].tolist() == [0, 0, 0] and bgr[0, 1].tolist() == [255, 255, 255]
+    assert bgr[0, 3].tolist() == [0, 0, 254]                       # BT.601 red (Y 81, U 90, V 240) -> B, G, R: (65*1220542 + 112*1673527 + 2^19) >> 20
+    assert preprocess.nv12_to_bgr(y, uv, [0], [0], chan_order=1)[0, 3].tolist() == [254, 0, 0]
+    planes = (np.arange(2 * 6 * 4) % 256).astype(np.uint8).reshape(2, 6, 4)      # two 4x4 NV12 frames
+    p = str(tmp_path / "n.cdraw")
+    rawvideo.write_raw_video(p, planes, fps=24, chan_order=rawvideo.NV12)
+    cap = rawvideo.RawVideoCapture(p)
+    assert cap.nv12 and (cap.width, cap.height, cap.length) == (4, 4, 2)
+    out = np.zeros((2, 3, 4), np.uint8)
+    assert cap.read_batch_into(out, [1, 3, 5]) == 2 and (out == planes[:, [1, 3, 5]]).all()
+    with pytest.raises(ValueError):
+        rawvideo.write_raw_video(p, planes[:, :5], chan_order=rawvideo.NV12)

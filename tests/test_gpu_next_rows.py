@@ -166,3 +166,77 @@ def test_rle_one_16m_frame_segment(engine):
     te = engine.rle(cls, mx)
     assert te["run_lengths"].cpu().tolist() == [n // 2, 1, n - n // 2 - 1]
     assert te["score_means"][1].item() == mx[n // 2].item()
+
+
+# ----------------------------------------------------------------------------- NV12 ingest
+def _bgr_to_nv12(frames):
+    """Test helper: BT.601 limited-range NV12 planes [n, H*3/2, W] from BGR frames (float math,
+    2x2 chroma average); only used to make plausible NV12 input."""
+    f = frames.astype(np.float64)
+    b, g, r = f[..., 0], f[..., 1], f[..., 2]
+    y = 16 + 0.257 * r + 0.504 * g + 0.098 * b
+    u = 128 - 0.148 * r - 0.291 * g + 0.439 * b
+    v = 128 + 0.439 * r - 0.368 * g - 0.071 * b
+    n, h, w = y.shape
+    pool = lambda a: a.reshape(n, h // 2, 2, w // 2, 2).mean(axis=(2, 4))  # noqa: E731
+    uv = np.empty((n, h // 2, w), np.float64)
+    uv[:, :, 0::2], uv[:, :, 1::2] = pool(u), pool(v)
+    return np.clip(np.rint(np.concatenate([y, uv], axis=1)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("h,w,order", [(720, 1280, 0), (36, 62, 1), (8, 6, 0)])
+def test_nv12_conversion_is_bit_exact(engine, h, w, order):
+    from oracle import preprocess
+    rs = np.random.RandomState(h + w)
+    planes = rs.randint(0, 256, size=(3, h * 3 // 2, w)).astype(np.uint8)      # every byte value, every combination
+    dev = torch.from_numpy(planes).to(engine.device)
+    got = engine.nv12_to_bgr(dev[:, :h], dev[:, h:], chan_order=order).cpu().numpy()
+    want = np.stack([preprocess.nv12_to_bgr(p[:h], p[h:], chan_order=order) for p in planes])
+    assert got.shape == (3, h, w, 3) and (got == want).all()
+    # selected rows, from planes with padded row strides (views into wider buffers)
+    yr = np.array(sorted(rs.choice(h, size=max(2, h // 5), replace=False)), dtype=np.int32)
+    ur = (yr // 2).astype(np.int32)
+    wide = torch.zeros((3, h * 3 // 2, w + 10), dtype=torch.uint8, device=engine.device)
+    wide[:, :, 1:w + 1] = dev
+    view = wide[:, :, 1:w + 1]                                                 # rows start at an odd address
+    got = engine.nv12_to_bgr(view[:, :h], view[:, h:], torch.from_numpy(yr).to(engine.device),
+                             torch.from_numpy(ur).to(engine.device), chan_order=order).cpu().numpy()
+    want = np.stack([preprocess.nv12_to_bgr(p[:h], p[h:], yr, ur, chan_order=order) for p in planes])
+    assert (got == want).all()
+
+
+def test_nv12_container_end_to_end(engine, tmp_path):
+    """A 720p NV12 clip: sampled-row plane upload + GPU conversion + classify gives the logits of
+    converting whole frames with the oracle and classifying those; the CLI segments it."""
+    from cutdet import rawvideo, synth as csynth
+    from frameID.data import VideoDataset
+    from frameID.net import load_default_net
+    from oracle import net as onet, preprocess, segmentation, synth
+    runs = [(0, 110), (2, 12), (1, 120)]
+    cl = csynth.classes_from_runs(runs)
+    planes = _bgr_to_nv12(synth.clip(SEED, cl, 720, 1280))
+    path = str(tmp_path / "clip_nv12.cdraw")
+    rawvideo.write_raw_video(path, planes, chan_order=rawvideo.NV12)
+    bgr = np.stack([preprocess.nv12_to_bgr(p[:720], p[720:]) for p in planes])
+    w = onet.load_blob()
+    want = np.concatenate([onet.forward(w, preprocess.preprocess_batch(bgr[a:a + 22])).numpy()
+                           for a in range(0, len(cl), 22)])
+    net, _ = load_default_net()
+    net.eval().to(engine.device)
+    for sampled in (True, False):
+        ds = VideoDataset(path, resize=256, device=engine.device)
+        assert ds.nv12 and ds.video_info == {"fps": 30, "length": len(cl), "width": 1280, "height": 720}
+        got = []
+        for b in ds.frame_batches(64, sampled=sampled):
+            assert tuple(b.shape[1:]) == ((144 if sampled else 720), 1280, 3)
+            got.append(net.classify_frames(b, chan_order=ds.chan_order, net_h=ds.batch_net_height)[0])
+        got = torch.cat(got).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-3
+    assert want.argmax(1).tolist() == cl                      # the round trip through NV12 keeps the classes
+    mod = _cli()
+    out = mod.main(mod.sv_parser.parse_args([path, "--batch-size", "64"]))
+    assert open(out, "rb").read() == segmentation.segment_clip(want)[3]
+    # the reference-style iterator over an NV12 container yields the float frames of the converted clip
+    it = iter(VideoDataset(path, resize=256, device=engine.device))
+    first = next(it).cpu().numpy()
+    assert first.tobytes() == preprocess.preprocess(bgr[0]).tobytes()
