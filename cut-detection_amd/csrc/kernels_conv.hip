@@ -38,43 +38,61 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 // v_mfma_f32_16x16x4_f32 (K slots 4e + kq), four bf16 values feed one v_mfma_f32_16x16x16_bf16
 // (K slots 4kq + e) - the same four input channels either way, so both precisions share every
 // index computation.  Accumulation is fp32 in both.
-template <bool BF> struct Prec;
-template <> struct Prec<false> {
+//
+// A third arithmetic, split bf16 ("x3"), keeps fp32's storage size and every address: each fp32
+// value v is stored as two bfloat16, hi = bf16(v) and lo = bf16(v - hi), and the 16-byte cell that
+// holds four fp32 channels in fp32 mode holds {hi x 4, lo x 4} of the same four channels.  A product
+// a*w is then formed on the bf16 matrix cores as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi (three
+// v_mfma_f32_16x16x16_bf16 instead of four v_mfma_f32_16x16x4_f32, each about 1.7x shorter); the
+// dropped a_lo*w_lo term and the representation error are each below 2^-16 of |a||w|.
+constexpr int kF32 = 0, kBF16 = 1, kX3 = 2;
+template <int P> struct Prec;
+template <> struct Prec<kF32> {
     typedef float elem; typedef f32x4 frag;
     static constexpr int kSub = 4;          // MFMAs per fragment pair
     static constexpr int kEs = 4;           // bytes per element
 };
-template <> struct Prec<true> {
+template <> struct Prec<kBF16> {
     typedef uint16_t elem; typedef bf16x4 frag;
     static constexpr int kSub = 1;
     static constexpr int kEs = 2;
+};
+template <> struct Prec<kX3> {
+    typedef uint32_t elem; typedef u32x4 frag;   // element = one channel's (hi, lo) pair, by size only
+    static constexpr int kSub = 3;
+    static constexpr int kEs = 4;
 };
 
 // Weight fragments are read through a buffer descriptor: the address is one per-lane VGPR
 // (lane * fragment bytes) plus a scalar offset, so the 81 loads of a tile cost no vector address
 // arithmetic and nothing for the compiler to hoist into registers.
-template <bool BF>
+template <int P>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* w) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 27 * 3 * 64 * 4 * Prec<BF>::kEs, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 27 * 3 * 64 * 4 * Prec<P>::kEs, 0x00020000);
 }
 // fragment `idx` (= step * 3 + n-tile) of a layer's packed weights
-template <bool BF>
-__device__ __forceinline__ typename Prec<BF>::frag load_frag(__amdgpu_buffer_rsrc_t r, int lane, int idx) {
-    if constexpr (BF)
+template <int P>
+__device__ __forceinline__ typename Prec<P>::frag load_frag(__amdgpu_buffer_rsrc_t r, int lane, int idx) {
+    if constexpr (P == kBF16)
         return __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8, idx * 512, 0));
     else
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
+        return __builtin_bit_cast(typename Prec<P>::frag, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-// sub-step e of a fragment pair (fp32: e = 0..3; bf16: e = 0 only)
-template <bool BF>
-__device__ __forceinline__ f32x4 mfma_frag(const typename Prec<BF>::frag& a, const typename Prec<BF>::frag& b, int e,
+// sub-step e of a fragment pair (fp32: e = 0..3; bf16: e = 0 only; split bf16: e = 0..2 = the
+// two small cross terms first, then hi x hi)
+template <int P>
+__device__ __forceinline__ f32x4 mfma_frag(const typename Prec<P>::frag& a, const typename Prec<P>::frag& b, int e,
                                            f32x4 c) {
-    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
-    else return mfma4(a[e], b[e], c);
+    if constexpr (P == kBF16) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    else if constexpr (P == kX3) {
+        const bf16x4 ah = __builtin_bit_cast(bf16x4, i32x2{(int)a[0], (int)a[1]}), al = __builtin_bit_cast(bf16x4, i32x2{(int)a[2], (int)a[3]});
+        const bf16x4 bh = __builtin_bit_cast(bf16x4, i32x2{(int)b[0], (int)b[1]}), bl = __builtin_bit_cast(bf16x4, i32x2{(int)b[2], (int)b[3]});
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(e == 0 ? al : ah, e == 1 ? bl : bh, c, 0, 0, 0);
+    } else return mfma4(a[e], b[e], c);
 }
 // two fp32 values -> two bf16 (round to nearest even) in one dword, `lo` in the low half
 // (compiles to v_cvt_pk_bf16_f32; written as a conversion, not inline asm, so that the compiler
@@ -83,6 +101,14 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     const bf16x2 v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, v);
+}
+
+// four fp32 values -> one split-bf16 cell {hi x 4, lo x 4}: hi = bf16(v), lo = bf16(v - hi)
+__device__ __forceinline__ u32x4 split_bf16(const f32x4 v) {
+    const uint32_t h01 = pack_bf16(v[0], v[1]), h23 = pack_bf16(v[2], v[3]);
+    const float r0 = v[0] - __uint_as_float(h01 << 16), r1 = v[1] - __uint_as_float(h01 & 0xFFFF0000u);
+    const float r2 = v[2] - __uint_as_float(h23 << 16), r3 = v[3] - __uint_as_float(h23 & 0xFFFF0000u);
+    return u32x4{h01, h23, pack_bf16(r0, r1), pack_bf16(r2, r3)};
 }
 
 // Pool-window max of one lane: columns 3*wi .. 3*wi+2 of its 12 columns, rows t = 0..2.
@@ -290,12 +316,12 @@ __device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__
 #ifndef CD_C1_LB
 #define CD_C1_LB 4
 #endif
-template <int MODE, bool OBF>
+template <int MODE, int OBF>
 __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
     int chan_order, const float* __restrict__ wfrag, typename Prec<OBF>::elem* __restrict__ out, int n, int H, int Hp,
     int chunks, int groups, int cpw) {
-    typedef typename Prec<OBF>::elem elem;       // the arithmetic is fp32 either way; OBF stores bf16
+    typedef typename Prec<OBF>::elem elem;       // the arithmetic is fp32 either way; OBF is the storage format
     __shared__ __attribute__((aligned(16))) float tile[kC1Tile];
     __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];   // per-wave 16x16 transposes
     __shared__ float spost[3 * kC];               // bias / BN scale / BN shift (registers are scarcer)
@@ -468,8 +494,10 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
                 {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + (lane >> 2) * 16 + 4 * (lane & 3));
                     if (st_ok) {
-                        if constexpr (OBF)
+                        if constexpr (OBF == kBF16)
                             *reinterpret_cast<uint2*>(st_ptr + nt * 16) = uint2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                        else if constexpr (OBF == kX3)
+                            *reinterpret_cast<u32x4*>(st_ptr + nt * 16) = split_bf16(v);
                         else
                             *reinterpret_cast<f32x4*>(st_ptr + nt * 16) = v;
                     }
@@ -618,8 +646,11 @@ static void launch_conv1(const cd_handle* h, unsigned grid, hipStream_t s, const
         hipLaunchKernelGGL((conv1_bf16_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), 0, s, x, src, sa, frame_stride,
                            chan_order, reinterpret_cast<const bf16x4*>(h->p.w1b), (const float*)h->p.post,
                            reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks);
+    else if (h->dtype == CD_BF16X3)
+        hipLaunchKernelGGL((conv1_kernel<MODE, kX3>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
+                           (const float*)h->p.w1, reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw);
     else
-        hipLaunchKernelGGL((conv1_kernel<MODE, false>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
+        hipLaunchKernelGGL((conv1_kernel<MODE, kF32>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
                            (const float*)h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw);
 }
 
@@ -656,7 +687,7 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
 // LDS reads, three weight loads that hit L1/L2) are requested during the MFMAs of step s and first
 // used after them.  The scheduling barriers keep the compiler from sinking the loads down to
 // their first use, which would expose the L2 latency once per step.
-template <int PITCH, bool BF>
+template <int PITCH, int BF>
 __device__ __forceinline__ void conv48_load_step(const typename Prec<BF>::elem* patch, const int (&base)[3],
                                                  __amdgpu_buffer_rsrc_t wr, int lane, int s,
                                                  typename Prec<BF>::frag (&a)[3][3], typename Prec<BF>::frag (&b)[3]) {
@@ -673,7 +704,7 @@ __device__ __forceinline__ void conv48_load_step(const typename Prec<BF>::elem* 
 }
 
 // Steps S0 .. S1-1 of the 27 (a K range: the accumulators then hold a partial sum).
-template <int PITCH, bool BF, int S0 = 0, int S1 = 27>
+template <int PITCH, int BF, int S0 = 0, int S1 = 27>
 __device__ __forceinline__ void conv48_wave_tile(const typename Prec<BF>::elem* patch, const int (&base)[3],
                                                  __amdgpu_buffer_rsrc_t wr, int lane, f32x4 (&acc)[3][3][3]) {
     typedef typename Prec<BF>::frag frag;
@@ -729,21 +760,21 @@ constexpr int kP2 = 14;
 constexpr int kG2Pix = kP2 * kP2;              // 196 pixels
 // per precision: 16-byte pieces of one channel group of a patch (16 channels x element size per
 // pixel), wave-wide DMA instructions that copy them, and the LDS buffer padded to whole instructions
-template <bool BF> struct G2 {
+template <int BF> struct G2 {
     static constexpr int kEs = Prec<BF>::kEs;
     static constexpr int kPieces = kG2Pix * kEs;            // 784 fp32, 392 bf16
     static constexpr int kDma = (kPieces + 63) / 64;        // 13 fp32, 7 bf16
     static constexpr int kBufElems = kDma * 1024 / kEs;
 };
 
-template <bool BF> struct Conv2Tile { const char* src; typename Prec<BF>::elem* dst; int ty, tx; };
+template <int BF> struct Conv2Tile { const char* src; typename Prec<BF>::elem* dst; int ty, tx; };
 
 // LDS-DMA of one channel group of a patch: wave-wide 16-byte copies, LDS image linear.
 // All 64 lanes take part in the last copy as well (no exec-masked region: a branch here makes the
 // compiler shuttle all 108 accumulators between AGPRs and VGPRs once per unit): its surplus
 // pieces read the first pixels of patch rows 14 and 15, which exist (next rows of the padded frame
 // or the slack frame), and land in the padding at the end of the LDS buffer.
-template <bool BF>
+template <int BF>
 __device__ __forceinline__ void conv2_dma_group(const char* src, typename Prec<BF>::elem* dst,
                                                 const int (&rel)[G2<BF>::kDma], int lane) {
     char* d = reinterpret_cast<char*>(dst);
@@ -761,7 +792,7 @@ __device__ __forceinline__ void conv2_dma_group(const char* src, typename Prec<B
 // zero as its C operand, so the accumulators are defined and consumed inside one tile body and
 // never cross the loop edge (the compiler otherwise permutes all 108 of them through VGPRs once
 // per unit).
-template <int G, bool BF>
+template <int G, int BF>
 __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, int mine_off, int other_off,
                                            const char* next_src, const int (&rel)[G2<BF>::kDma],
                                            const int (&base)[3], __amdgpu_buffer_rsrc_t wr, int lane,
@@ -822,7 +853,7 @@ __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, 
 
 // pooled + normalised results of one wave tile -> HBM, transposed through `scratch` (3 KB of an
 // idle patch buffer) so that each pool window's 48 channels leave as 16-byte stores
-template <bool BF>
+template <int BF>
 __device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc)[3][3][3],
                                                const float* post, const Conv2Tile<BF>& t, int Hp,
                                                int lane) {
@@ -838,7 +869,7 @@ __device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if constexpr (BF) {
+    if constexpr (BF == kBF16) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int f = it * 64 + lane;                 // 16-byte piece f (8 channels) of 16 windows x 96 bytes
@@ -857,15 +888,19 @@ __device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc
             const int win = f / 12, c4 = f % 12;
             const int py = t.ty * 4 + (win >> 2), px = t.tx * 4 + (win & 3);
             const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + win * kC + 4 * c4);
-            if (py < Hp && px < kW2)
-                *reinterpret_cast<f32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = v;
+            if (py < Hp && px < kW2) {
+                if constexpr (BF == kX3)
+                    *reinterpret_cast<u32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = split_bf16(v);
+                else
+                    *reinterpret_cast<f32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = v;
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool BF>
+template <int BF>
 __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem* __restrict__ in,
                                                    typename Prec<BF>::elem* __restrict__ out,
                                                    const void* __restrict__ wfrag,
@@ -1003,11 +1038,15 @@ int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     const int cap = h->dtype == CD_BF16 ? CD_C2_BF16_WAVES : 1024;
     const int grid = total < cap ? total : cap;
     if (h->dtype == CD_BF16)
-        hipLaunchKernelGGL(conv2_kernel<true>, dim3((unsigned)grid), dim3(64), 0, s,
+        hipLaunchKernelGGL(conv2_kernel<kBF16>, dim3((unsigned)grid), dim3(64), 0, s,
                            reinterpret_cast<const uint16_t*>(h->act1), reinterpret_cast<uint16_t*>(h->act2),
                            (const void*)h->p.w2b, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
+    else if (h->dtype == CD_BF16X3)
+        hipLaunchKernelGGL(conv2_kernel<kX3>, dim3((unsigned)grid), dim3(64), 0, s,
+                           reinterpret_cast<const uint32_t*>(h->act1), reinterpret_cast<uint32_t*>(h->act2),
+                           (const void*)h->p.w2x, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     else
-        hipLaunchKernelGGL(conv2_kernel<false>, dim3((unsigned)grid), dim3(64), 0, s, (const float*)h->act1, h->act2,
+        hipLaunchKernelGGL(conv2_kernel<kF32>, dim3((unsigned)grid), dim3(64), 0, s, (const float*)h->act1, h->act2,
                            (const void*)h->p.w2, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     CD_HIP(hipGetLastError());
     return CD_OK;
@@ -1024,7 +1063,7 @@ int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 constexpr int kP3W = kW2 + 2;   // 30
 
-template <bool BF>
+template <int BF>
 __global__ __launch_bounds__(256) void conv3_head_kernel(
     const typename Prec<BF>::elem* __restrict__ in, const void* __restrict__ wfrag, const float* __restrict__ post,
     const float* __restrict__ fc0w, const float* __restrict__ fc0p, const float* __restrict__ fc1w,
@@ -1119,7 +1158,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     // steps, plus the hand-over of its partial sums through LDS; 21 measured best of 19..23).
     constexpr int kSplit = 21;
     if (spare_off >= 0) {
-        if constexpr (!BF) {
+        if constexpr (BF != kBF16) {
             // wave 3 keeps at most two tiles' partial sums in registers: the first tile's go to a
             // spare LDS buffer behind the head's arrays as soon as they are complete
             f32x4* spare = reinterpret_cast<f32x4*>(smem + spare_off);   // [27 accumulators][64 lanes]
@@ -1229,9 +1268,11 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
 // The head kernel needs more dynamic LDS than the default limit; the limit is a per-device
 // attribute of the kernel, so this runs once per handle with the handle's device current.
 int init_conv3_head() {
-    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<false>),
+    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<kF32>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<true>),
+    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<kBF16>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<kX3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     return CD_OK;
 }
@@ -1254,11 +1295,15 @@ int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logit
         lds = (size_t)spare_off * 4 + part;
     }
     if (bf)
-        hipLaunchKernelGGL(conv3_head_kernel<true>, dim3((unsigned)n), dim3(256), lds, s,
+        hipLaunchKernelGGL(conv3_head_kernel<kBF16>, dim3((unsigned)n), dim3(256), lds, s,
                            reinterpret_cast<const uint16_t*>(h->act2), (const void*)h->p.w3b, h->p.post + 6 * kC,
                            h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3, spare_off);
+    else if (h->dtype == CD_BF16X3)
+        hipLaunchKernelGGL(conv3_head_kernel<kX3>, dim3((unsigned)n), dim3(256), lds, s,
+                           reinterpret_cast<const uint32_t*>(h->act2), (const void*)h->p.w3x, h->p.post + 6 * kC,
+                           h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3, spare_off);
     else
-        hipLaunchKernelGGL(conv3_head_kernel<false>, dim3((unsigned)n), dim3(256), lds, s, (const float*)h->act2,
+        hipLaunchKernelGGL(conv3_head_kernel<kF32>, dim3((unsigned)n), dim3(256), lds, s, (const float*)h->act2,
                            (const void*)h->p.w3, h->p.post + 6 * kC, h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b,
                            logits, maxv, argmax, g.h2, g.h3, spare_off);
     CD_HIP(hipGetLastError());
