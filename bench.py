@@ -83,8 +83,8 @@ def parse(argv=None):
     ap.add_argument("--timing-every", type=int, default=1,
                     help="with --stage-timing dominant: bracket every n-th launch of the dominant kernel "
                          "(the roofline's launch time is the average over that sample)")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
-                    help="f32 is the headline (the reference's arithmetic); bf16 / bf16x3 run the library's "
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16_split"], default="f32",
+                    help="f32 is the headline (the reference's arithmetic); bf16 / bf16_split run the library's "
                          "bf16 matrix-core modes - separate, non-headline measurements")
     ap.add_argument("--independent-clips", action="store_true",
                     help="multi-GPU: every rank segments its own clip (no stream gather, no collective at all)")
@@ -396,7 +396,7 @@ def main():
         bytes_frame = compulsory_bytes(args.height, args.width, net_h)
         if args.dtype != "f32" or (args.height, args.width) != (H0, W0):
             traffic = None          # the committed PMC figure is of the fp32 720p kernel
-        arith = {"f32": "fp32", "bf16": "bf16-matrix-core", "bf16x3": "split-bf16 (3 products) matrix-core"}[args.dtype]
+        arith = {"f32": "fp32", "bf16": "bf16-matrix-core", "bf16_split": "split-bf16 (hi+lo, 4 products) matrix-core"}[args.dtype]
         out = {
             "metric": f"frames/sec classified+segmented, {args.width}x{args.height} RGB",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

@@ -74,8 +74,8 @@ struct DeviceParams {
     uint16_t* w1b;  // conv1 B fragments in bf16: [3 ky][3 n-tiles][64 lanes][4] (kx = lane>>4, channel e; zero pads)
     uint16_t* w2b;  // conv2 / conv3 B fragments in bf16: [27 steps][3 n-tiles][64 lanes][4]
     uint16_t* w3b;
-    uint32_t* w2x;  // conv2 / conv3 B fragments as split bf16: [27 steps][3 n-tiles][64 lanes][hi x 4 | lo x 4]
-    uint32_t* w3x;
+    uint32_t* w2s;  // conv2 / conv3 B fragments as split bf16: [27 steps][3 n-tiles][hi | lo][64 lanes][w x 4, w x 4]
+    uint32_t* w3s;
     float* post;  // [3 layers][3][48]: conv bias, BN scale, BN shift
     float* fc0w;  // [32][768]
     float* fc0p;  // [3][32]: bias, BN scale, BN shift

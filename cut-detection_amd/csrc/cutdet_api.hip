@@ -45,7 +45,7 @@ void bn_affine(const float* g, const float* beta, const float* mu, const float* 
     }
 }
 
-struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b, w1b, w2x, w3x; };
+struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b, w1b, w2s, w3s; };
 
 // float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 and torch's .bfloat16() do)
 static uint16_t bf16_rne(float f) {
@@ -123,21 +123,25 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
         uint16_t* d = reinterpret_cast<uint16_t*>(&img[dst]);
         for (size_t k = 0; k < (size_t)27 * 3 * 64 * 4; ++k) d[k] = bf16_rne(img[src + k]);
     }
-    // the same fragments as split bf16: per lane {hi x 4, lo x 4}, hi = bf16(w), lo = bf16(w - hi)
-    const size_t o_w2x = section(27 * 3 * 64 * 4), o_w3x = section(27 * 3 * 64 * 4);
+    // the same fragments as split bf16, hi = bf16(w), lo = bf16(w - hi): per fragment two 1 KB pieces,
+    // lane entries {hi x 4, hi x 4} and {lo x 4, lo x 4} (each half meets one half of the activation cell)
+    const size_t o_w2s = section(27 * 3 * 64 * 8), o_w3s = section(27 * 3 * 64 * 8);
     for (int l = 1; l < 3; ++l) {
-        const size_t src = l == 1 ? o_w2 : o_w3, dst = l == 1 ? o_w2x : o_w3x;
+        const size_t src = l == 1 ? o_w2 : o_w3, dst = l == 1 ? o_w2s : o_w3s;
         uint16_t* d = reinterpret_cast<uint16_t*>(&img[dst]);
-        for (size_t f = 0; f < (size_t)27 * 3 * 64; ++f)
-            for (int e = 0; e < 4; ++e) {
-                const float w = img[src + 4 * f + e];
-                const uint16_t hi = bf16_rne(w);
-                uint32_t hb = (uint32_t)hi << 16;
-                float hf;
-                std::memcpy(&hf, &hb, 4);
-                d[8 * f + e] = hi;
-                d[8 * f + 4 + e] = bf16_rne(w - hf);
-            }
+        for (size_t f = 0; f < (size_t)27 * 3; ++f)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const float w = img[src + (f * 64 + lane) * 4 + e];
+                    const uint16_t hi = bf16_rne(w);
+                    const uint32_t hb = (uint32_t)hi << 16;
+                    float hf;
+                    std::memcpy(&hf, &hb, 4);
+                    const uint16_t lo = bf16_rne(w - hf);
+                    uint16_t* ph = d + (f * 2 * 64 + lane) * 8, *pl = d + ((f * 2 + 1) * 64 + lane) * 8;
+                    ph[e] = ph[4 + e] = hi;
+                    pl[e] = pl[4 + e] = lo;
+                }
     }
     // block 1 in bf16: fragment (ky, nt), lane (kx = lane>>4, col): W[16nt+col][ci = e][ky][kx], zero for kx = 3 / e = 3
     const size_t o_w1b = section(9 * 64 * 2);
@@ -170,7 +174,7 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     std::memcpy(&img[o_fc1b], fc1b, kOut * sizeof(float));
     for (int k = 0; k < 256; ++k) img[o_lut + k] = (float)k / 255.0f;   // data.py:227 divides, it does not scale
 
-    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b, o_w1b, o_w2x, o_w3x};
+    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b, o_w1b, o_w2s, o_w3s};
     return img;
 }
 
@@ -358,7 +362,7 @@ const char* cd_last_error(void) { return cd::g_err; }
 int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int device, int dtype) {
     if (!out || !weights_blob) { set_error("cd_create: null argument"); return CD_EINVAL; }
     *out = nullptr;
-    if (dtype != CD_F32 && dtype != CD_BF16 && dtype != CD_BF16X3) {
+    if (dtype != CD_F32 && dtype != CD_BF16 && dtype != CD_BF16_SPLIT) {
         set_error("cd_create: dtype %d not supported (0 = f32, 1 = bf16, 2 = split bf16)", dtype);
         return CD_EINVAL;
     }
@@ -398,7 +402,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->p.fc1b = base + off.fc1b; h->p.lut = base + off.lut;
     h->p.w1b = reinterpret_cast<uint16_t*>(base + off.w1b);
     h->p.w2b = reinterpret_cast<uint16_t*>(base + off.w2b); h->p.w3b = reinterpret_cast<uint16_t*>(base + off.w3b);
-    h->p.w2x = reinterpret_cast<uint32_t*>(base + off.w2x); h->p.w3x = reinterpret_cast<uint32_t*>(base + off.w3x);
+    h->p.w2s = reinterpret_cast<uint32_t*>(base + off.w2s); h->p.w3s = reinterpret_cast<uint32_t*>(base + off.w3s);
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);
     const size_t t_short = align_up((size_t)2 * kMaxSrcW * sizeof(short), 256);

@@ -39,28 +39,36 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 // (K slots 4kq + e) - the same four input channels either way, so both precisions share every
 // index computation.  Accumulation is fp32 in both.
 //
-// A third arithmetic, split bf16 ("x3"), keeps fp32's storage size and every address: each fp32
-// value v is stored as two bfloat16, hi = bf16(v) and lo = bf16(v - hi), and the 16-byte cell that
-// holds four fp32 channels in fp32 mode holds {hi x 4, lo x 4} of the same four channels.  A product
-// a*w is then formed on the bf16 matrix cores as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi (three
-// v_mfma_f32_16x16x16_bf16 instead of four v_mfma_f32_16x16x4_f32, each about 1.7x shorter); the
-// dropped a_lo*w_lo term and the representation error are each below 2^-16 of |a||w|.
-constexpr int kF32 = 0, kBF16 = 1, kX3 = 2;
+// A third arithmetic, split bf16, keeps fp32's storage size and every address: each fp32 value v
+// is stored as two bfloat16, hi = bf16(v) and lo = bf16(v - hi), and the 16-byte cell that holds
+// four fp32 channels in fp32 mode holds {hi x 4, lo x 4} of the same four channels.  That cell is,
+// as it stands, a lane's A operand of v_mfma_f32_16x16x32_bf16 (8 K slots per lane: which channel
+// sits in which slot is free as long as A and B agree).  With the weights packed as {w_hi x 4,
+// w_hi x 4} and {w_lo x 4, w_lo x 4}, two such MFMAs give
+//     (a_hi + a_lo) * w_hi + (a_hi + a_lo) * w_lo,
+// the complete product of the split values, in 2 x 16 cycles where fp32 needs 4 x 32.  What is lost
+// is only the splitting itself: |v - (hi + lo)| <= 2^-17 |v|.
+constexpr int kF32 = 0, kBF16 = 1, kS2 = 2;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct SplitB { u32x4 h, l; };       // B fragments of one (step, n-tile): {w_hi, w_hi} and {w_lo, w_lo}
 template <int P> struct Prec;
 template <> struct Prec<kF32> {
-    typedef float elem; typedef f32x4 frag;
+    typedef float elem; typedef f32x4 frag; typedef f32x4 bfrag;
     static constexpr int kSub = 4;          // MFMAs per fragment pair
     static constexpr int kEs = 4;           // bytes per element
+    static constexpr int kWBytes = 16;      // bytes of one lane's B fragment
 };
 template <> struct Prec<kBF16> {
-    typedef uint16_t elem; typedef bf16x4 frag;
+    typedef uint16_t elem; typedef bf16x4 frag; typedef bf16x4 bfrag;
     static constexpr int kSub = 1;
     static constexpr int kEs = 2;
+    static constexpr int kWBytes = 8;
 };
-template <> struct Prec<kX3> {
-    typedef uint32_t elem; typedef u32x4 frag;   // element = one channel's (hi, lo) pair, by size only
-    static constexpr int kSub = 3;
+template <> struct Prec<kS2> {
+    typedef uint32_t elem; typedef u32x4 frag; typedef SplitB bfrag;   // element = one channel's (hi, lo), by size only
+    static constexpr int kSub = 2;
     static constexpr int kEs = 4;
+    static constexpr int kWBytes = 32;
 };
 
 // Weight fragments are read through a buffer descriptor: the address is one per-lane VGPR
@@ -68,31 +76,33 @@ template <> struct Prec<kX3> {
 // arithmetic and nothing for the compiler to hoist into registers.
 template <int P>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* w) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 27 * 3 * 64 * 4 * Prec<P>::kEs, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 27 * 3 * 64 * Prec<P>::kWBytes, 0x00020000);
 }
 // fragment `idx` (= step * 3 + n-tile) of a layer's packed weights
 template <int P>
-__device__ __forceinline__ typename Prec<P>::frag load_frag(__amdgpu_buffer_rsrc_t r, int lane, int idx) {
+__device__ __forceinline__ typename Prec<P>::bfrag load_frag(__amdgpu_buffer_rsrc_t r, int lane, int idx) {
     if constexpr (P == kBF16)
         return __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8, idx * 512, 0));
+    else if constexpr (P == kS2)      // [idx][hi | lo][lane][16 bytes]
+        return SplitB{__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 2048, 0)),
+                      __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 2048 + 1024, 0))};
     else
-        return __builtin_bit_cast(typename Prec<P>::frag, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-// sub-step e of a fragment pair (fp32: e = 0..3; bf16: e = 0 only; split bf16: e = 0..2 = the
-// two small cross terms first, then hi x hi)
+// sub-step e of a fragment pair (fp32: e = 0..3; bf16: e = 0 only; split bf16: e = 0 the w_lo
+// terms, e = 1 the w_hi terms)
 template <int P>
-__device__ __forceinline__ f32x4 mfma_frag(const typename Prec<P>::frag& a, const typename Prec<P>::frag& b, int e,
+__device__ __forceinline__ f32x4 mfma_frag(const typename Prec<P>::frag& a, const typename Prec<P>::bfrag& b, int e,
                                            f32x4 c) {
     if constexpr (P == kBF16) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
-    else if constexpr (P == kX3) {
-        const bf16x4 ah = __builtin_bit_cast(bf16x4, i32x2{(int)a[0], (int)a[1]}), al = __builtin_bit_cast(bf16x4, i32x2{(int)a[2], (int)a[3]});
-        const bf16x4 bh = __builtin_bit_cast(bf16x4, i32x2{(int)b[0], (int)b[1]}), bl = __builtin_bit_cast(bf16x4, i32x2{(int)b[2], (int)b[3]});
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(e == 0 ? al : ah, e == 1 ? bl : bh, c, 0, 0, 0);
-    } else return mfma4(a[e], b[e], c);
+    else if constexpr (P == kS2)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, e == 0 ? b.l : b.h), c, 0, 0, 0);
+    else return mfma4(a[e], b[e], c);
 }
 // two fp32 values -> two bf16 (round to nearest even) in one dword, `lo` in the low half
 // (compiles to v_cvt_pk_bf16_f32; written as a conversion, not inline asm, so that the compiler
@@ -161,6 +171,9 @@ __device__ __forceinline__ void xcd_frame_tile(int b, int per_frame, int& frame,
 // 4-byte load at any byte address (the hardware handles unaligned global loads)
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
+#ifndef CD_DIAG_P
+#define CD_DIAG_P 0      // diagnostic builds: the arithmetic (0 fp32, 1 bf16, 2 split bf16) whose blocks 2 / 3 write time stamps
+#endif
 #ifndef CD_C1_CPW
 #define CD_C1_CPW 1
 #endif
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
                     if (st_ok) {
                         if constexpr (OBF == kBF16)
                             *reinterpret_cast<uint2*>(st_ptr + nt * 16) = uint2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                        else if constexpr (OBF == kX3)
+                        else if constexpr (OBF == kS2)
                             *reinterpret_cast<u32x4*>(st_ptr + nt * 16) = split_bf16(v);
                         else
                             *reinterpret_cast<f32x4*>(st_ptr + nt * 16) = v;
@@ -646,8 +659,8 @@ static void launch_conv1(const cd_handle* h, unsigned grid, hipStream_t s, const
         hipLaunchKernelGGL((conv1_bf16_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), 0, s, x, src, sa, frame_stride,
                            chan_order, reinterpret_cast<const bf16x4*>(h->p.w1b), (const float*)h->p.post,
                            reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks);
-    else if (h->dtype == CD_BF16X3)
-        hipLaunchKernelGGL((conv1_kernel<MODE, kX3>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
+    else if (h->dtype == CD_BF16_SPLIT)
+        hipLaunchKernelGGL((conv1_kernel<MODE, kS2>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
                            (const float*)h->p.w1, reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw);
     else
         hipLaunchKernelGGL((conv1_kernel<MODE, kF32>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
@@ -690,7 +703,7 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
 template <int PITCH, int BF>
 __device__ __forceinline__ void conv48_load_step(const typename Prec<BF>::elem* patch, const int (&base)[3],
                                                  __amdgpu_buffer_rsrc_t wr, int lane, int s,
-                                                 typename Prec<BF>::frag (&a)[3][3], typename Prec<BF>::frag (&b)[3]) {
+                                                 typename Prec<BF>::frag (&a)[3][3], typename Prec<BF>::bfrag (&b)[3]) {
     typedef typename Prec<BF>::frag frag;
     const int kk = s / 3, g = s % 3;
     const int off = ((kk / 3) * PITCH + (kk % 3)) * kC + 16 * g;
@@ -709,7 +722,8 @@ __device__ __forceinline__ void conv48_wave_tile(const typename Prec<BF>::elem* 
                                                  __amdgpu_buffer_rsrc_t wr, int lane, f32x4 (&acc)[3][3][3]) {
     typedef typename Prec<BF>::frag frag;
     constexpr int kM = 27 * Prec<BF>::kSub;      // MFMAs per step
-    frag a[2][3][3], b[2][3];
+    frag a[2][3][3];
+    typename Prec<BF>::bfrag b[2][3];
     conv48_load_step<PITCH, BF>(patch, base, wr, lane, S0, a[S0 & 1], b[S0 & 1]);
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
@@ -796,7 +810,7 @@ template <int G, int BF>
 __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, int mine_off, int other_off,
                                            const char* next_src, const int (&rel)[G2<BF>::kDma],
                                            const int (&base)[3], __amdgpu_buffer_rsrc_t wr, int lane,
-                                           typename Prec<BF>::frag (&a)[2][3][3], typename Prec<BF>::frag (&b)[2][3],
+                                           typename Prec<BF>::frag (&a)[2][3][3], typename Prec<BF>::bfrag (&b)[2][3],
                                            f32x4 (&acc)[3][3][3], unsigned long long* st = nullptr) {
     typedef typename Prec<BF>::frag frag;
     typedef typename Prec<BF>::elem elem;
@@ -833,16 +847,26 @@ __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, 
             if (m < n_side) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (m < 3) {
+#ifdef CD_EXP_NOB
+                    b[c ^ 1][m] = b[c][m];
+#else
                     b[c ^ 1][m] = load_frag<BF>(wr, lane, (nk * 3 + ng) * 3 + m);
+#endif
                 } else if (m < 12) {
                     const int lt = (m - 3) / 3, lj = (m - 3) % 3;
+#ifdef CD_EXP_NOA
+                    a[c ^ 1][lt][lj] = a[c][lt][lj];
+#else
                     a[c ^ 1][lt][lj] = *reinterpret_cast<const frag*>(bufs + ab[lj] + off + lt * kP2 * 16);
+#endif
                 } else {
                     const int it = m - 12;
+#ifndef CD_EXP_NODMA
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(next_src + (uint32_t)rel[it]),
                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(const_cast<elem*>(bufs) + other_off) + it * 1024),
                         16, 0, 0);
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -889,7 +913,7 @@ __device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc
             const int py = t.ty * 4 + (win >> 2), px = t.tx * 4 + (win & 3);
             const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + win * kC + 4 * c4);
             if (py < Hp && px < kW2) {
-                if constexpr (BF == kX3)
+                if constexpr (BF == kS2)
                     *reinterpret_cast<u32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = split_bf16(v);
                 else
                     *reinterpret_cast<f32x4*>(t.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = v;
@@ -952,7 +976,7 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     // diagnostic build (fp32 only): time stamps of the first 400 waves go to the slack frame behind the batch
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(out + (int64_t)n * out_frame) + 32 * blockIdx.x;
     int nstamp = 0;
-#define CD_STAMP() do { if (!BF && lane == 0 && nstamp < 32 && blockIdx.x < 200) stamps[nstamp] = __builtin_amdgcn_s_memrealtime(); ++nstamp; } while (0)
+#define CD_STAMP() do { if (BF == CD_DIAG_P && lane == 0 && nstamp < 32 && blockIdx.x < 200) stamps[nstamp] = __builtin_amdgcn_s_memrealtime(); ++nstamp; } while (0)
 #else
 #define CD_STAMP() do { } while (0)
 #endif
@@ -962,7 +986,8 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     Conv2Tile<BF> nxt = locate(next_id);
     // everything the first step needs from global memory is requested together: the patch copy,
     // step 0's weight fragments and the affine terms share one round trip
-    frag a[2][3][3], b[2][3];
+    frag a[2][3][3];
+    typename Prec<BF>::bfrag b[2][3];
     f32x4 acc[3][3][3];
     conv2_dma_group<BF>(cur.src, bufs, rel, lane);
 #pragma unroll
@@ -992,9 +1017,12 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
 #pragma unroll
             for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(a[0][t][j]));
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) asm volatile("" : "+v"(b[0][nt]));
+        for (int nt = 0; nt < 3; ++nt) {
+            if constexpr (BF == kS2) { asm volatile("" : "+v"(b[0][nt].h)); asm volatile("" : "+v"(b[0][nt].l)); }
+            else asm volatile("" : "+v"(b[0][nt]));
+        }
 #ifdef CD_DIAG
-        unsigned long long* stp = (!BF && blockIdx.x < 200 && nstamp == 14) ? stamps + 6400 : nullptr;   // third tile
+        unsigned long long* stp = (BF == CD_DIAG_P && blockIdx.x < 200 && nstamp == 14) ? stamps + 6400 : nullptr;   // third tile
         conv2_unit<0, BF>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc, stp);
         CD_STAMP();
         conv2_unit<1, BF>(bufs, second, first, cur.src + 2 * kGroupBytes, rel, base, wr, lane, a, b, acc, stp ? stp + 10 : nullptr);
@@ -1041,10 +1069,10 @@ int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
         hipLaunchKernelGGL(conv2_kernel<kBF16>, dim3((unsigned)grid), dim3(64), 0, s,
                            reinterpret_cast<const uint16_t*>(h->act1), reinterpret_cast<uint16_t*>(h->act2),
                            (const void*)h->p.w2b, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
-    else if (h->dtype == CD_BF16X3)
-        hipLaunchKernelGGL(conv2_kernel<kX3>, dim3((unsigned)grid), dim3(64), 0, s,
+    else if (h->dtype == CD_BF16_SPLIT)
+        hipLaunchKernelGGL(conv2_kernel<kS2>, dim3((unsigned)grid), dim3(64), 0, s,
                            reinterpret_cast<const uint32_t*>(h->act1), reinterpret_cast<uint32_t*>(h->act2),
-                           (const void*)h->p.w2x, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
+                           (const void*)h->p.w2s, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     else
         hipLaunchKernelGGL(conv2_kernel<kF32>, dim3((unsigned)grid), dim3(64), 0, s, (const float*)h->act1, h->act2,
                            (const void*)h->p.w2, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
@@ -1087,7 +1115,7 @@ __global__ __launch_bounds__(256) void conv3_head_kernel(
     // diagnostic build: per-wave time stamps go to the slack frame behind the batch's activations
     unsigned long long* st3 = reinterpret_cast<unsigned long long*>(const_cast<elem*>(in) + (int64_t)gridDim.x * (Hin + 2) * kP3W * kC) + (blockIdx.x * 4 + wave) * 8;
     int nst3 = 0;
-#define CD_STAMP3() do { if (!BF && lane == 0 && blockIdx.x < 400) st3[nst3] = __builtin_amdgcn_s_memrealtime(); ++nst3; } while (0)
+#define CD_STAMP3() do { if (BF == CD_DIAG_P && lane == 0 && blockIdx.x < 400) st3[nst3] = __builtin_amdgcn_s_memrealtime(); ++nst3; } while (0)
 #else
 #define CD_STAMP3() do { } while (0)
 #endif
@@ -1272,7 +1300,7 @@ int init_conv3_head() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<kBF16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<kX3>),
+    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_head_kernel<kS2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     return CD_OK;
 }
@@ -1298,9 +1326,9 @@ int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logit
         hipLaunchKernelGGL(conv3_head_kernel<kBF16>, dim3((unsigned)n), dim3(256), lds, s,
                            reinterpret_cast<const uint16_t*>(h->act2), (const void*)h->p.w3b, h->p.post + 6 * kC,
                            h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3, spare_off);
-    else if (h->dtype == CD_BF16X3)
-        hipLaunchKernelGGL(conv3_head_kernel<kX3>, dim3((unsigned)n), dim3(256), lds, s,
-                           reinterpret_cast<const uint32_t*>(h->act2), (const void*)h->p.w3x, h->p.post + 6 * kC,
+    else if (h->dtype == CD_BF16_SPLIT)
+        hipLaunchKernelGGL(conv3_head_kernel<kS2>, dim3((unsigned)n), dim3(256), lds, s,
+                           reinterpret_cast<const uint32_t*>(h->act2), (const void*)h->p.w3s, h->p.post + 6 * kC,
                            h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3, spare_off);
     else
         hipLaunchKernelGGL(conv3_head_kernel<kF32>, dim3((unsigned)n), dim3(256), lds, s, (const float*)h->act2,

@@ -19,8 +19,8 @@ lib = C.CDLL(LIB_PATH)
 CD_OK, CD_EINVAL, CD_EHIP, CD_ECAP, CD_ENOMEM = 0, -1, -2, -3, -4
 CD_F32 = 0
 CD_BF16 = 1
-CD_BF16X3 = 2
-DTYPES = {"f32": CD_F32, "bf16": CD_BF16, "bf16x3": CD_BF16X3}
+CD_BF16_SPLIT = 2
+DTYPES = {"f32": CD_F32, "bf16": CD_BF16, "bf16_split": CD_BF16_SPLIT}
 CD_BGR, CD_RGB = 0, 1
 STAGES = ("preprocess", "conv1", "conv2", "conv3_head", "rle")
 

@@ -65,10 +65,11 @@ enum {
  * matrix cores with fp32 accumulation; bias, pooling/affine epilogues and the head stay fp32.
  * Logits then differ from the fp32 result by a few 1e-2; class ids are unchanged on inputs with
  * clear margins.
- * CD_BF16X3: blocks 2 and 3 multiply fp32 values split into two bfloat16 terms each (hi + lo) as
- * three bf16 matrix-core products with fp32 accumulation; block 1, epilogues and head are fp32.
- * Logits stay within 1e-3 of the fp32 result (measured: a few 1e-5 on the test clips). */
-enum { CD_F32 = 0, CD_BF16 = 1, CD_BF16X3 = 2 };
+ * CD_BF16_SPLIT: blocks 2 and 3 multiply fp32 values split into two bfloat16 terms each
+ * (v = hi + lo to 2^-17) on the bf16 matrix cores, all four partial products, fp32 accumulation;
+ * block 1, epilogues and head are fp32.  Logits stay within 1e-3 of the fp32 result (measured: a
+ * few 1e-5 on the test clips). */
+enum { CD_F32 = 0, CD_BF16 = 1, CD_BF16_SPLIT = 2 };
 enum { CD_BGR = 0, CD_RGB = 1 };         /* channel order of u8 frames in memory */
 
 int cd_version(void);

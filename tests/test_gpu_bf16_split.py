@@ -20,7 +20,7 @@ LOGIT_TOL = 1e-3
 @pytest.fixture(scope="module")
 def engines():
     from cutdet import api
-    return api.default_engine("cuda:0"), api.default_engine("cuda:0", "bf16x3")
+    return api.default_engine("cuda:0"), api.default_engine("cuda:0", "bf16_split")
 
 
 def _uniform_input(n, h=144, w=256):
@@ -42,7 +42,7 @@ def test_x3_matches_reference_logits(engines, golden_dir, case):
     logits, mx, am = ex.forward_u8(frames)
     y = logits.cpu().numpy()
     err = float(np.abs(y - g[f"logits_{case}"]).max())
-    print(f"bf16x3 {case}: max |logit - reference| = {err:.2e}; vs fp32 kernels "
+    print(f"bf16_split {case}: max |logit - reference| = {err:.2e}; vs fp32 kernels "
           f"{float((logits - e32.forward_u8(frames)[0]).abs().max()):.2e}")
     assert err <= LOGIT_TOL, err
     assert am.cpu().tolist() == m["classes"]

@@ -3,10 +3,13 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cut-detection_amd"))
-os.environ["CUTDET_LIB"] = os.path.join(ROOT, "cut-detection_amd", "lib", "variants", "libcutdet_diag.so")
+# usage: diag_conv2.py [dtype] [variant]   (the variant must be built with -DCD_DIAG -DCD_DIAG_P=<0|1|2> for that dtype)
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else "f32"
+os.environ["CUTDET_LIB"] = os.path.join(ROOT, "cut-detection_amd", "lib", "variants",
+                                        "libcutdet_%s.so" % (sys.argv[2] if len(sys.argv) > 2 else "diag"))
 import torch
 from cutdet import api, _lib
-eng = api.default_engine("cuda:0")
+eng = api.default_engine("cuda:0", DTYPE)
 n = 256
 frames = eng.synth_frames(torch.zeros(n, dtype=torch.uint8, device="cuda"), 720, 1280)
 for _ in range(40):
