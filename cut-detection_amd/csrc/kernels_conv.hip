@@ -253,9 +253,10 @@ __device__ __forceinline__ void point_commit(T* tile, int tid, PointRaw& raw, co
     if (tid < kC1Rows) put_pixel(tile, tid, 256, raw.v[kC1Rows] >> c.sh2, bgr);
 }
 
-// MODE 2: general fixed-point bilinear / 2x2 box.  The two horizontally adjacent source pixels of
-// a tap pair are 6 contiguous bytes, fetched as one unaligned 8-byte load per source row; all 22
-// loads of a column are in flight before the first is used.  Arithmetic as sample_u8().
+// MODE 3: general fixed-point bilinear / 2x2 box straight from global memory (the fallback for
+// source rows that are not 16-byte aligned or too wide to stage).  The two horizontally adjacent
+// source pixels of a tap pair are 6 contiguous bytes, fetched as one unaligned 8-byte load per source
+// row; all 22 loads of a column are in flight before the first is used.  Arithmetic as sample_u8().
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 
 template <typename T>
@@ -306,6 +307,83 @@ __device__ __forceinline__ void generic_stage(T* tile, const uint8_t* __restrict
     }
 }
 
+// MODE 2: the same arithmetic with coalesced loads.  For each of the tile's 11 rows the workgroup
+// copies the two source rows it blends into LDS with 16-byte loads (every byte of a row is fetched
+// once, by consecutive lanes), then each thread picks its two horizontally adjacent source pixels -
+// 6 contiguous bytes - out of LDS as three aligned dwords per source row.  `stage` holds two rows of
+// `pitch` bytes (a multiple of 16, at least 16 beyond the row).  Needs 16-byte aligned source rows.
+template <typename T>
+__device__ __forceinline__ void staged_rows_stage(T* tile, uint8_t* stage, int pitch, const uint8_t* __restrict__ fsrc,
+                                                  const SampleArgs& sa, int gy0, int H, int tid, bool bgr) {
+    const int chunks = (sa.W0 * 3 + 15) >> 4;            // 16-byte pieces per source row (the tail piece reads
+                                                         // into the next row or the slack the caller guarantees)
+    // this thread's column(s): LDS column tid (network column tid - 1) and, for tid 0, column 256 as well
+    int c0s[2], a0s[2], a1s[2], offs[2], sh0s[2], sh1s[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = k == 0 ? tid : 256, gxc = max(c - 1, 0);
+        c0s[k] = sa.mode == 2 ? 2 * gxc : sa.sx[gxc];
+        a0s[k] = sa.mode == 2 ? 1 : sa.ax[2 * gxc];
+        a1s[k] = sa.mode == 2 ? 1 : sa.ax[2 * gxc + 1];
+        const int byte0 = c0s[k] * 3;
+        offs[k] = byte0 & ~3;                              // aligned dword that holds the first byte
+        sh0s[k] = (byte0 & 3) * 8;                         // bit offset of pixel c0 in the 12 bytes read
+        sh1s[k] = c0s[k] + 1 < sa.W0 ? sh0s[k] + 24 : sh0s[k];   // pixel c0 + 1 (c0 again at the right border)
+    }
+    for (int r = 0; r < kC1Rows; ++r) {
+        const int gy = gy0 + r;
+        const bool yin = gy >= 0 && gy < H;                // uniform over the workgroup
+        int b0 = 1, b1 = 1;
+        if (yin) {
+            int r0, r1;
+            if (sa.mode == 2) { r0 = 2 * gy; r1 = 2 * gy + 1; }
+            else {
+                const int sy = sa.sy[gy];
+                r0 = min(max(sy, 0), sa.H0 - 1); r1 = min(max(sy + 1, 0), sa.H0 - 1);
+                b0 = sa.by[2 * gy]; b1 = sa.by[2 * gy + 1];
+            }
+            const uint4* g0 = reinterpret_cast<const uint4*>(fsrc + (int64_t)r0 * sa.row_stride);
+            const uint4* g1 = reinterpret_cast<const uint4*>(fsrc + (int64_t)r1 * sa.row_stride);
+            __syncthreads();                               // the previous row's taps are done with the staging rows
+            for (int c = tid; c < chunks; c += 256) {
+                reinterpret_cast<uint4*>(stage)[c] = g0[c];
+                reinterpret_cast<uint4*>(stage + pitch)[c] = g1[c];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k == 1 && tid != 0) break;
+            const int c = k == 0 ? tid : 256;
+            uint32_t px = 0;
+            if (yin && c >= 1) {
+                const uint32_t* t = reinterpret_cast<const uint32_t*>(stage + offs[k]);
+                const uint32_t* bt = reinterpret_cast<const uint32_t*>(stage + pitch + offs[k]);
+                const uint64_t tlo = t[0] | ((uint64_t)t[1] << 32), blo = bt[0] | ((uint64_t)bt[1] << 32);
+                const uint32_t thi = t[2], bhi = bt[2];
+                // 9 bytes starting at bit sh0 of the 12 read: pixel c0 = bits 0..23, pixel c0 + 1 = bits 24..47
+                const uint64_t top = sh0s[k] ? (tlo >> sh0s[k]) | ((uint64_t)thi << (64 - sh0s[k])) : tlo;
+                const uint64_t bot = sh0s[k] ? (blo >> sh0s[k]) | ((uint64_t)bhi << (64 - sh0s[k])) : blo;
+                const int d = sh1s[k] - sh0s[k];           // 24, or 0 at the right border
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const int p00 = (int)((top >> (8 * cc)) & 255), p01 = (int)((top >> (d + 8 * cc)) & 255);
+                    const int p10 = (int)((bot >> (8 * cc)) & 255), p11 = (int)((bot >> (d + 8 * cc)) & 255);
+                    int v;
+                    if (sa.mode == 2) v = (p00 + p01 + p10 + p11 + 2) >> 2;
+                    else {
+                        const int S0 = p00 * a0s[k] + p01 * a1s[k], S1 = p10 * a0s[k] + p11 * a1s[k];
+                        v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                        v = min(max(v, 0), 255);
+                    }
+                    px |= (uint32_t)v << (8 * cc);
+                }
+            }
+            put_pixel(tile, r, c, px, bgr);
+        }
+    }
+}
+
 // MODE 0: normalised fp32 NCHW input, row-wise copy.
 __device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__ fx, int gy0, int H, int tid) {
     for (int idx = tid; idx < kInC * kC1Rows * 258; idx += 256) {
@@ -319,7 +397,8 @@ __device__ __forceinline__ void f32_stage(float* tile, const float* __restrict__
 }
 
 // MODE 0: fp32 NCHW input.  MODE 1: u8 source, pure point sample (every tap weight is 1).
-// MODE 2: u8 source, general resize.
+// MODE 2: u8 source, general resize, source rows staged in LDS (dynamic shared memory: two rows).
+// MODE 3: u8 source, general resize, per-thread gathers.
 //
 // A workgroup walks `cpw` consecutive chunks of one frame (one by default: with one chunk per
 // workgroup the staging of one workgroup overlaps the MFMA phases of the three others on the CU, and
@@ -333,7 +412,8 @@ template <int MODE, int OBF>
 __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
     int chan_order, const float* __restrict__ wfrag, typename Prec<OBF>::elem* __restrict__ out, int n, int H, int Hp,
-    int chunks, int groups, int cpw) {
+    int chunks, int groups, int cpw, int stage_pitch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_stage[];   // MODE 2: two source rows
     typedef typename Prec<OBF>::elem elem;       // the arithmetic is fp32 either way; OBF is the storage format
     __shared__ __attribute__((aligned(16))) float tile[kC1Tile];
     __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];   // per-wave 16x16 transposes
@@ -422,6 +502,7 @@ __global__ __launch_bounds__(256, CD_C1_LB) void conv1_kernel(
 #endif
         if (MODE == 0) f32_stage(tile, fx, gy0, H, tid);
         else if (MODE == 1) point_commit(tile, tid, raw, pcol, bgr);
+        else if (MODE == 2) staged_rows_stage(tile, dyn_stage, stage_pitch, fsrc, sa, gy0, H, tid, bgr);
         else generic_stage(tile, fsrc, sa, gy0, H, tid, bgr);
 #ifdef CD_DIAG
         if (!OBF && tid == 0 && kc == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
@@ -550,7 +631,8 @@ template <int MODE>
 __global__ __launch_bounds__(256, 4) void conv1_bf16_kernel(
     const float* __restrict__ x, const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride,
     int chan_order, const bf16x4* __restrict__ wfrag, const float* __restrict__ post, uint16_t* __restrict__ out,
-    int n, int H, int Hp, int chunks) {
+    int n, int H, int Hp, int chunks, int stage_pitch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_stage[];   // MODE 2: two source rows
     __shared__ __attribute__((aligned(16))) uint2 tile[kC1Rows * kC1RSB];
     __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];   // per-wave 16x16 transposes
     __shared__ float spost[3 * kC];
@@ -586,6 +668,7 @@ __global__ __launch_bounds__(256, 4) void conv1_bf16_kernel(
 
     if (MODE == 0) f32_stage_bf16(tile, fx, gy0, H, tid);
     else if (MODE == 1) point_commit(tile, tid, raw, pcol, bgr);
+    else if (MODE == 2) staged_rows_stage(tile, dyn_stage, stage_pitch, fsrc, sa, gy0, H, tid, bgr);
     else generic_stage(tile, fsrc, sa, gy0, H, tid, bgr);
     __syncthreads();
 
@@ -654,17 +737,19 @@ static int c1_chunks_per_wg(int n, int chunks) {
 template <int MODE>
 static void launch_conv1(const cd_handle* h, unsigned grid, hipStream_t s, const float* x, const uint8_t* src,
                          const SampleArgs& sa, int64_t frame_stride, int chan_order, int n, const Geometry& g,
-                         int chunks, int groups, int cpw) {
+                         int chunks, int groups, int cpw, int stage_pitch = 0) {
+    const size_t dyn = (size_t)2 * stage_pitch;
     if (h->dtype == CD_BF16)
-        hipLaunchKernelGGL((conv1_bf16_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), 0, s, x, src, sa, frame_stride,
+        hipLaunchKernelGGL((conv1_bf16_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), dyn, s, x, src, sa, frame_stride,
                            chan_order, reinterpret_cast<const bf16x4*>(h->p.w1b), (const float*)h->p.post,
-                           reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks);
+                           reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks, stage_pitch);
     else if (h->dtype == CD_BF16_SPLIT)
-        hipLaunchKernelGGL((conv1_kernel<MODE, kS2>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
-                           (const float*)h->p.w1, reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw);
+        hipLaunchKernelGGL((conv1_kernel<MODE, kS2>), dim3(grid), dim3(256), dyn, s, x, src, sa, frame_stride, chan_order,
+                           (const float*)h->p.w1, reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw,
+                           stage_pitch);
     else
-        hipLaunchKernelGGL((conv1_kernel<MODE, kF32>), dim3(grid), dim3(256), 0, s, x, src, sa, frame_stride, chan_order,
-                           (const float*)h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw);
+        hipLaunchKernelGGL((conv1_kernel<MODE, kF32>), dim3(grid), dim3(256), dyn, s, x, src, sa, frame_stride, chan_order,
+                           (const float*)h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw, stage_pitch);
 }
 
 int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s) {
@@ -683,8 +768,17 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
                   h->rt.affine, h->rt.xm, h->rt.xa, h->rt.ym, h->rt.ya};
     const int cpw = c1_chunks_per_wg(n, chunks), groups = (chunks + cpw - 1) / cpw;
     if (W0 < 3) { set_error("cd_forward_u8: source frames must be at least 3 pixels wide"); return CD_EINVAL; }
+    // General resize: source rows go through LDS when they are 16-byte aligned and two of them fit
+    // 24 KB (sources up to 4096 pixels wide); the last 16-byte piece of a row may reach up to 15 bytes
+    // past it, which stays inside the frame except on the last row of the last frame - there the
+    // per-thread gather variant runs instead (it never reads past a row).
+    const int row_bytes = W0 * 3, pitch = ((row_bytes + 15) & ~15) + 16;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
+    const bool tail_ok = (row_bytes & 15) == 0 || row_stride >= (int64_t)((row_bytes + 15) & ~15);
     if (h->rt.mode == 1) launch_conv1<1>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
-    else launch_conv1<2>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
+    else if (aligned && tail_ok && 2 * pitch <= 24 * 1024)
+        launch_conv1<2>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw, pitch);
+    else launch_conv1<3>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }

@@ -98,7 +98,7 @@ def test_create_rejects_unknown_dtype():
     from cutdet import _lib, api
     h = C.c_void_p(0)
     blob = api.default_blob()
-    rc = _lib.lib.cd_create(C.byref(h), blob, len(blob), 0, 2)
+    rc = _lib.lib.cd_create(C.byref(h), blob, len(blob), 0, 3)
     assert rc == _lib.CD_EINVAL and b"dtype" in _lib.lib.cd_last_error()
     with pytest.raises(ValueError):
         from cutdet.engine import Engine

@@ -104,6 +104,23 @@ def test_forward_u8_matches_reference_logits(engine, golden_dir, case):
     assert y2.tobytes() == y.tobytes()
 
 
+@pytest.mark.parametrize("h,w,pad", [(90, 161, 0), (180, 320, 5), (1080, 1920, 16), (100, 300, 0)])
+def test_fused_general_resize_row_layouts(engine, h, w, pad):
+    """The fused general resize has two staging routes: source rows through LDS (16-byte aligned
+    rows) and per-thread gathers (anything else: odd widths, views at odd offsets).  Both must give
+    the bits of the two-kernel route, whose resize is checked byte for byte against the oracle."""
+    from oracle import synth
+    frames = torch.from_numpy(synth.clip(SEED, [0, 1, 2, 1, 0], h, w)).to(engine.device)
+    want = engine.forward(engine.preprocess(frames))
+    if pad:
+        wide = torch.zeros((5, h, w + pad + 1, 3), dtype=torch.uint8, device=engine.device)
+        view = wide[:, :, 1:w + 1] if pad % 16 else wide[:, :, :w]      # odd pads: rows start off 16-byte boundaries
+        view.copy_(frames)
+        frames = view
+    got = engine.forward_u8(frames)[0]
+    assert torch.equal(got, want)
+
+
 def test_forward_matches_oracle_mixed_batch(engine, oracle_weights):
     from oracle import net as onet
     x = _uniform_input(37)                               # odd batch size
