@@ -45,7 +45,7 @@ void bn_affine(const float* g, const float* beta, const float* mu, const float* 
     }
 }
 
-struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b, w1b, w2s, w3s; };
+struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b, w1b, w2s, w3s, w1s; };
 
 // float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 and torch's .bfloat16() do)
 static uint16_t bf16_rne(float f) {
@@ -156,6 +156,26 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
                         d[((ky * 3 + nt) * 64 + lane) * 4 + e] = bf16_rne(v);
                     }
     }
+    // block 1 for split bf16 on u8 input: the bytes enter the matrix core as they are, so the weights carry
+    // the 1/255: w' = w / 255 (fp32), fragment (ky, nt), lane (kx = lane>>4, col): {hi(w'[ci=0..2]), 0, lo(...), 0}
+    const size_t o_w1s = section(9 * 64 * 4);
+    {
+        uint16_t* d = reinterpret_cast<uint16_t*>(&img[o_w1s]);
+        for (int ky = 0; ky < 3; ++ky)
+            for (int nt = 0; nt < 3; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int kx = lane >> 4, oc = 16 * nt + (lane & 15);
+                        const float w = (kx < 3 && e < 3) ? cv[0].w[oc * 27 + e * 9 + ky * 3 + kx] / 255.0f : 0.f;
+                        const uint16_t hi = bf16_rne(w);
+                        const uint32_t hb = (uint32_t)hi << 16;
+                        float hf;
+                        std::memcpy(&hf, &hb, 4);
+                        uint16_t* cell = d + ((ky * 3 + nt) * 64 + lane) * 8;
+                        cell[e] = hi;
+                        cell[4 + e] = bf16_rne(w - hf);
+                    }
+    }
     for (int l = 0; l < 3; ++l) {
         float* p = &img[o_post + (size_t)l * 3 * kC];
         std::memcpy(p, cv[l].b, kC * sizeof(float));
@@ -174,7 +194,7 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     std::memcpy(&img[o_fc1b], fc1b, kOut * sizeof(float));
     for (int k = 0; k < 256; ++k) img[o_lut + k] = (float)k / 255.0f;   // data.py:227 divides, it does not scale
 
-    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b, o_w1b, o_w2s, o_w3s};
+    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b, o_w1b, o_w2s, o_w3s, o_w1s};
     return img;
 }
 
@@ -402,6 +422,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->p.fc1b = base + off.fc1b; h->p.lut = base + off.lut;
     h->p.w1b = reinterpret_cast<uint16_t*>(base + off.w1b);
     h->p.w2b = reinterpret_cast<uint16_t*>(base + off.w2b); h->p.w3b = reinterpret_cast<uint16_t*>(base + off.w3b);
+    h->p.w1s = reinterpret_cast<uint32_t*>(base + off.w1s);
     h->p.w2s = reinterpret_cast<uint32_t*>(base + off.w2s); h->p.w3s = reinterpret_cast<uint32_t*>(base + off.w3s);
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);

@@ -239,6 +239,14 @@ __device__ __forceinline__ void put_pixel(uint2* tile, int r, int c, uint32_t px
     tile[r * kC1RSB + c] = uint2{pack_bf16(bgr ? f2 : f0, f1), pack_bf16(bgr ? f0 : f2, 0.f)};
 }
 
+// Tile of the split-bf16 block-1 kernel: one 16-byte cell per pixel, {R, G, B, 0, R, G, B, 0} with the
+// byte values themselves (0..255 are exact in bfloat16; the 1/255 is folded into the weights).
+__device__ __forceinline__ void put_pixel(u32x4* tile, int r, int c, uint32_t px, bool bgr) {
+    const float f0 = (float)(px & 255u), f1 = (float)((px >> 8) & 255u), f2 = (float)((px >> 16) & 255u);
+    const uint32_t rg = pack_bf16(bgr ? f2 : f0, f1), b0 = pack_bf16(bgr ? f0 : f2, 0.f);
+    tile[r * kC1RSB + c] = u32x4{rg, b0, rg, b0};
+}
+
 template <typename T>
 __device__ __forceinline__ void point_commit(T* tile, int tid, PointRaw& raw, const PointCol& c, bool bgr) {
     // (each row's conversion is pinned behind the previous row's LDS writes: scheduled freely, the
@@ -725,6 +733,111 @@ __global__ __launch_bounds__(256, 4) void conv1_bf16_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Block 1 in split-bf16 mode (u8 sources only): the workgroup / wave-tile / epilogue structure of the
+// bf16 kernel on v_mfma_f32_16x16x32_bf16.  The input needs no splitting - a byte value is exact in
+// bfloat16 - so the tile holds the bytes as they are and the weights carry the 1/255: w' = w / 255 in
+// fp32, split into hi + lo bfloat16.  A lane's A operand is the pixel's 16-byte cell
+// {R, G, B, 0, R, G, B, 0} at (row + ky, col + kq); its B operand is {w'_hi(R, G, B), 0, w'_lo(R, G, B), 0}
+// of tap (ky, kx = kq) (zero for kq = 3): one MFMA per kernel row adds byte x (w'_hi + w'_lo), and
+// every product is exact in the fp32 accumulator.  K = 27 in three MFMAs of 16 cycles each, where
+// fp32 takes seven of 32.  Output cells are split bf16 like the other blocks' inputs.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void conv1_split_kernel(
+    const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride, int chan_order,
+    const u32x4* __restrict__ wfrag, const float* __restrict__ post, uint32_t* __restrict__ out,
+    int n, int H, int Hp, int chunks, int stage_pitch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_stage[];   // MODE 2: two source rows
+    __shared__ __attribute__((aligned(16))) u32x4 tile[kC1Rows * kC1RSB];
+    __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];   // per-wave 16x16 transposes
+    __shared__ float spost[3 * kC];
+    const int tid = threadIdx.x;
+    int frame, chunk;
+    xcd_frame_tile(blockIdx.x, chunks, frame, chunk);
+    if (frame >= n) return;
+    const bool bgr = chan_order == CD_BGR;
+    const uint8_t* fsrc = src + (int64_t)frame * frame_stride;
+    const int py0 = chunk * kC1PoolRows;
+    const int gy0 = 3 * py0 - 1;            // input row held in tile row 0
+
+    PointRaw raw;
+    PointCol pcol{};
+    if (MODE == 1) {
+        pcol = point_columns(sa, tid);
+#pragma unroll
+        for (int u = 0; u < kC1Rows + 1; ++u) raw.v[u] = point_fetch_piece(fsrc, sa, pcol, gy0, H, tid, u);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int q = lane >> 4, ch = lane & 15;
+    uint32_t* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
+    float* my_out = scratch + wave * 256;
+    // B fragments (ky, n-tile) stay in registers; bias and BatchNorm terms go to LDS
+    u32x4 bw[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) bw[ky][nt] = wfrag[(ky * 3 + nt) * 64 + lane];
+    if (tid < 3 * kC) spost[tid] = post[tid];
+
+    if (MODE == 1) point_commit(tile, tid, raw, pcol, bgr);
+    else if (MODE == 2) staged_rows_stage(tile, dyn_stage, stage_pitch, fsrc, sa, gy0, H, tid, bgr);
+    else generic_stage(tile, fsrc, sa, gy0, H, tid, bgr);
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {            // wave tile wt = wave + 4k
+        int wt = wave + 4 * k;
+        asm volatile("" : "+v"(wt));         // keeps the compiler from hoisting all four tiles' addresses
+        int base[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c12 = 4 * j + (i & 3), d = (c12 * 11) >> 5, m = c12 - 3 * d;   // d = c12 / 3
+            const int W = min(16 * wt + 4 * (i >> 2) + d, kC1Windows - 1);
+            const int wr = (W >= kW1 ? 1 : 0) + (W >= 2 * kW1 ? 1 : 0);               // W / 85
+            // (lanes kq = 3 carry zero weights and re-read the kq = 2 cell, which is always written)
+            base[j] = 3 * wr * kC1RSB + 3 * (W - wr * kW1) + m + min(kq, 2);
+        }
+        const int Ws = 16 * wt + (lane >> 2);
+        const int wrs = (Ws >= kW1 ? 1 : 0) + (Ws >= 2 * kW1 ? 1 : 0);
+        const bool st_ok = Ws < kC1Windows && py0 + wrs < Hp;
+        uint32_t* st_ptr = fout + ((int64_t)(py0 + wrs + 1) * kP1W + (Ws - wrs * kW1) + 1) * kC + 4 * (lane & 3);
+        u32x4 a[5][3];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[r][j] = tile[base[j] + r * kC1RSB];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const float bias = spost[nt * 16 + ch];
+            const f32x4 bias4 = f32x4{bias, bias, bias, bias};
+            f32x4 acc[3][3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t + ky][j]),
+                                                                            __builtin_bit_cast(bf16x8, bw[ky][nt]),
+                                                                            ky == 0 ? bias4 : acc[t][j], 0, 0, 0);
+            const float sc = spost[kC + nt * 16 + ch], sh = spost[2 * kC + nt * 16 + ch];
+            float m[4] = {window_max<0>(acc), window_max<1>(acc), window_max<2>(acc), window_max<3>(acc)};
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) my_out[(4 * q + wi) * 16 + ch] = fmaf(m[wi], sc, sh);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + (lane >> 2) * 16 + 4 * (lane & 3));
+                if (st_ok) *reinterpret_cast<u32x4*>(st_ptr + nt * 16) = split_bf16(v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read done before the next group rewrites
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 static unsigned xcd_grid(int n, int per_frame) { return (unsigned)(((n + 7) / 8) * 8 * per_frame); }
 
 // Chunks per workgroup: as many as still leave four workgroups for every CU (the most that fit),
@@ -732,6 +845,14 @@ static unsigned xcd_grid(int n, int per_frame) { return (unsigned)(((n + 7) / 8)
 static int c1_chunks_per_wg(int n, int chunks) {
     const long total = (long)n * chunks;
     return (int)std::min<long>(kC1MaxChunksPerWG, std::max<long>(1, total / 1024));
+}
+
+// static LDS of the block-1 kernel a u8 forward of this arithmetic launches
+static int c1_static_lds(int dtype) {
+    const int common = 4 * 16 * 16 * 4 + 3 * kC * 4;
+    if (dtype == CD_BF16) return kC1Rows * kC1RSB * 8 + common;
+    if (dtype == CD_BF16_SPLIT) return kC1Rows * kC1RSB * 16 + common;
+    return kC1Tile * 4 + common;
 }
 
 template <int MODE>
@@ -743,10 +864,16 @@ static void launch_conv1(const cd_handle* h, unsigned grid, hipStream_t s, const
         hipLaunchKernelGGL((conv1_bf16_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), dyn, s, x, src, sa, frame_stride,
                            chan_order, reinterpret_cast<const bf16x4*>(h->p.w1b), (const float*)h->p.post,
                            reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks, stage_pitch);
-    else if (h->dtype == CD_BF16_SPLIT)
-        hipLaunchKernelGGL((conv1_kernel<MODE, kS2>), dim3(grid), dim3(256), dyn, s, x, src, sa, frame_stride, chan_order,
-                           (const float*)h->p.w1, reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw,
-                           stage_pitch);
+    else if (h->dtype == CD_BF16_SPLIT) {
+        if constexpr (MODE == 0)       // float frames are not exact in bfloat16: the fp32 block 1, split-bf16 output
+            hipLaunchKernelGGL((conv1_kernel<MODE, kS2>), dim3(grid), dim3(256), dyn, s, x, src, sa, frame_stride, chan_order,
+                               (const float*)h->p.w1, reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw,
+                               stage_pitch);
+        else
+            hipLaunchKernelGGL((conv1_split_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), dyn, s, src, sa, frame_stride,
+                               chan_order, reinterpret_cast<const u32x4*>(h->p.w1s), (const float*)h->p.post,
+                               reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, stage_pitch);
+    }
     else
         hipLaunchKernelGGL((conv1_kernel<MODE, kF32>), dim3(grid), dim3(256), dyn, s, x, src, sa, frame_stride, chan_order,
                            (const float*)h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw, stage_pitch);
@@ -769,14 +896,14 @@ int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W
     const int cpw = c1_chunks_per_wg(n, chunks), groups = (chunks + cpw - 1) / cpw;
     if (W0 < 3) { set_error("cd_forward_u8: source frames must be at least 3 pixels wide"); return CD_EINVAL; }
     // General resize: source rows go through LDS when they are 16-byte aligned and two of them fit
-    // 24 KB (sources up to 4096 pixels wide); the last 16-byte piece of a row may reach up to 15 bytes
+    // beside the kernel's static LDS in 64 KB (sources up to 4096 pixels wide in fp32, 2500 in split bf16); the last 16-byte piece of a row may reach up to 15 bytes
     // past it, which stays inside the frame except on the last row of the last frame - there the
     // per-thread gather variant runs instead (it never reads past a row).
     const int row_bytes = W0 * 3, pitch = ((row_bytes + 15) & ~15) + 16;
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     const bool tail_ok = (row_bytes & 15) == 0 || row_stride >= (int64_t)((row_bytes + 15) & ~15);
     if (h->rt.mode == 1) launch_conv1<1>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
-    else if (aligned && tail_ok && 2 * pitch <= 24 * 1024)
+    else if (aligned && tail_ok && 2 * pitch <= 65536 - c1_static_lds(h->dtype))
         launch_conv1<2>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw, pitch);
     else launch_conv1<3>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
     CD_HIP(hipGetLastError());
