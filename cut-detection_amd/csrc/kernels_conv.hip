@@ -57,18 +57,27 @@ template <> struct Prec<kF32> {
     static constexpr int kSub = 4;          // MFMAs per fragment pair
     static constexpr int kEs = 4;           // bytes per element
     static constexpr int kWBytes = 16;      // bytes of one lane's B fragment
+    static constexpr int kBDist = 1;        // block 2: steps a weight fragment is requested ahead of its use
+    static constexpr int kBLoads = 3;       // block 2: buffer loads per step
 };
 template <> struct Prec<kBF16> {
     typedef uint16_t elem; typedef bf16x4 frag; typedef bf16x4 bfrag;
     static constexpr int kSub = 1;
     static constexpr int kEs = 2;
     static constexpr int kWBytes = 8;
+    static constexpr int kBDist = 1;
+    static constexpr int kBLoads = 3;
 };
 template <> struct Prec<kS2> {
     typedef uint32_t elem; typedef u32x4 frag; typedef SplitB bfrag;   // element = one channel's (hi, lo), by size only
     static constexpr int kSub = 2;
     static constexpr int kEs = 4;
     static constexpr int kWBytes = 32;
+#ifndef CD_S2_BDIST
+#define CD_S2_BDIST 2
+#endif
+    static constexpr int kBDist = CD_S2_BDIST;   // a step is only ~860 cycles here: one step ahead does not cover an L2 round trip
+    static constexpr int kBLoads = 6;
 };
 
 // Weight fragments are read through a buffer descriptor: the address is one per-lane VGPR
@@ -1031,14 +1040,19 @@ template <int G, int BF>
 __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, int mine_off, int other_off,
                                            const char* next_src, const int (&rel)[G2<BF>::kDma],
                                            const int (&base)[3], __amdgpu_buffer_rsrc_t wr, int lane,
-                                           typename Prec<BF>::frag (&a)[2][3][3], typename Prec<BF>::bfrag (&b)[2][3],
+                                           typename Prec<BF>::frag (&a)[2][3][3],
+                                           typename Prec<BF>::bfrag (&b)[Prec<BF>::kBDist + 1][3],
                                            f32x4 (&acc)[3][3][3], unsigned long long* st = nullptr) {
     typedef typename Prec<BF>::frag frag;
     typedef typename Prec<BF>::elem elem;
     constexpr int kM = 27 * Prec<BF>::kSub;      // MFMAs per step
+    constexpr int kBD = Prec<BF>::kBDist, kNB = kBD + 1;
     if (st && lane == 0) st[9] = __builtin_amdgcn_s_memrealtime();
-    // everything outstanding was issued at least one step ago
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The patch copy issued in step 0 of the previous unit must have landed.  VMEM completes in issue
+    // order, so it is enough to wait for everything but the weight loads of the last kBD - 1 steps
+    // (with one step of look-ahead: everything; all of it was issued at least one step ago).
+    if constexpr (kBD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kBD - 1) * Prec<BF>::kBLoads) : "memory");
     int bm[3], bo[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { bm[j] = base[j] + mine_off; bo[j] = base[j] + other_off; }
@@ -1046,9 +1060,13 @@ __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, 
     for (int kk = 0; kk < 9; ++kk) {
         constexpr int kFirst = G * 9;
         const int c = (kFirst + kk) & 1;
+        // the weight fragments rotate through kBD + 1 register sets: this step's, and where the ones
+        // requested now (for kBD steps ahead; a tile is 27 steps, whatever tile follows) go
+        const int bc = kBD == 1 ? c : (kFirst + kk) % kNB, bn = kBD == 1 ? c ^ 1 : (kFirst + kk + kBD) % kNB;
+        const int bstep = (kFirst + kk + kBD) % 27, bg = bstep / 9, bk = bstep % 9;
         // Next step's operands: from this unit's patch, or (last step) from the next unit's
         const int* ab = kk < 8 ? bm : bo;
-        const int ng = kk < 8 ? G : (G + 1) % 3, nk = kk < 8 ? kk + 1 : 0;
+        const int nk = kk < 8 ? kk + 1 : 0;
         const int off = ((nk / 3) * kP2 + (nk % 3)) * 16;
         // The wave is alone on its SIMD, so whatever it issues between two MFMAs that takes longer
         // than the MFMA leaves the matrix pipe idle.  The step's memory instructions are therefore
@@ -1062,16 +1080,16 @@ __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, 
         for (int m = 0; m < kM; ++m) {
             const int e = m / 27, t = (m / 9) % 3, j = (m / 3) % 3, nt = m % 3;
             if (G == 0 && kk == 0 && e == 0)
-                acc[t][j][nt] = mfma_frag<BF>(a[c][t][j], b[c][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
+                acc[t][j][nt] = mfma_frag<BF>(a[c][t][j], b[bc][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
             else
-                acc[t][j][nt] = mfma_frag<BF>(a[c][t][j], b[c][nt], e, acc[t][j][nt]);
+                acc[t][j][nt] = mfma_frag<BF>(a[c][t][j], b[bc][nt], e, acc[t][j][nt]);
             if (m < n_side) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (m < 3) {
 #ifdef CD_EXP_NOB
-                    b[c ^ 1][m] = b[c][m];
+                    b[bn][m] = b[bc][m];
 #else
-                    b[c ^ 1][m] = load_frag<BF>(wr, lane, (nk * 3 + ng) * 3 + m);
+                    b[bn][m] = load_frag<BF>(wr, lane, (bk * 3 + bg) * 3 + m);
 #endif
                 } else if (m < 12) {
                     const int lt = (m - 3) / 3, lj = (m - 3) % 3;
@@ -1207,12 +1225,16 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     Conv2Tile<BF> nxt = locate(next_id);
     // everything the first step needs from global memory is requested together: the patch copy,
     // step 0's weight fragments and the affine terms share one round trip
+    constexpr int kBD = Prec<BF>::kBDist;
     frag a[2][3][3];
-    typename Prec<BF>::bfrag b[2][3];
+    typename Prec<BF>::bfrag b[kBD + 1][3];
     f32x4 acc[3][3][3];
     conv2_dma_group<BF>(cur.src, bufs, rel, lane);
+    // weight fragments of the first kBD steps (step s of a tile = kernel tap s % 9 of channel group s / 9)
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) b[0][nt] = load_frag<BF>(wr, lane, nt);
+    for (int s0 = 0; s0 < kBD; ++s0)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) b[s0][nt] = load_frag<BF>(wr, lane, ((s0 % 9) * 3 + s0 / 9) * 3 + nt);
     spost[lane] = post[lane];
     spost[64 + lane] = post[64 + lane];
     if (lane < 3 * kC - 128) spost[128 + lane] = post[128 + lane];
@@ -1238,10 +1260,12 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
 #pragma unroll
             for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(a[0][t][j]));
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) {
-            if constexpr (BF == kS2) { asm volatile("" : "+v"(b[0][nt].h)); asm volatile("" : "+v"(b[0][nt].l)); }
-            else asm volatile("" : "+v"(b[0][nt]));
-        }
+        for (int s0 = 0; s0 < kBD; ++s0)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                if constexpr (BF == kS2) { asm volatile("" : "+v"(b[s0][nt].h)); asm volatile("" : "+v"(b[s0][nt].l)); }
+                else asm volatile("" : "+v"(b[s0][nt]));
+            }
 #ifdef CD_DIAG
         unsigned long long* stp = (BF == CD_DIAG_P && blockIdx.x < 200 && nstamp == 14) ? stamps + 6400 : nullptr;   // third tile
         conv2_unit<0, BF>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc, stp);
@@ -1271,8 +1295,13 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int j = 0; j < 3; ++j) a[0][t][j] = a[1][t][j];
+        // (weight sets rotate with period kBD + 1: two sets flip like the operands, three sets come
+        // round exactly once per 27-step tile)
+        static_assert(kBD == 1 || 27 % (kBD + 1) == 0, "weight register sets must realign at a tile boundary");
+        if constexpr (kBD == 1) {
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) b[0][nt] = b[1][nt];
+            for (int nt = 0; nt < 3; ++nt) b[0][nt] = b[1][nt];
+        }
     }
     // the look-ahead copy and operand loads of a unit that will never run are still in flight
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
