@@ -123,9 +123,12 @@ def spawn_ranks(n):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
 
     def relay():
+        # only the JSON line belongs on stdout; whatever else a library prints there goes to stderr
         for line in procs[0].stdout:
-            sys.stdout.write(line.decode("utf-8", "replace"))
-            sys.stdout.flush()
+            text = line.decode("utf-8", "replace")
+            out = sys.stdout if text.lstrip().startswith("{") else sys.stderr
+            out.write(text)
+            out.flush()
 
     reader = threading.Thread(target=relay, daemon=True)
     reader.start()

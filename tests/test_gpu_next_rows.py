@@ -240,3 +240,42 @@ def test_nv12_container_end_to_end(engine, tmp_path):
     it = iter(VideoDataset(path, resize=256, device=engine.device))
     first = next(it).cpu().numpy()
     assert first.tobytes() == preprocess.preprocess(bgr[0]).tobytes()
+
+
+# ----------------------------------------------------------------------------- multi-rank shapes on one GPU
+def _bench_json(args, **env):
+    import subprocess
+    import sys
+    e = dict(os.environ, CUTDET_BENCH_BACKEND="gloo", CUTDET_BENCH_ONE_GPU="1", **env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True,
+                       timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0] == r.stdout.strip(), "stdout must hold the one JSON line and nothing else"
+    return json.loads(lines[0])
+
+
+def test_bench_full_game_shape_in_contiguous_ranges():
+    """The frame-range sharded shape (a game split into contiguous ranges, one all-gather of the
+    (class, max) streams, rank 0 segments the whole game) with two rank processes sharing this GPU
+    over gloo: the job must segment the game exactly as one process does."""
+    one = _bench_json(["--total-frames", "6000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    two = _bench_json(["--gpus", "2", "--total-frames", "6000", "--steps", "1", "--warmup", "1"])
+    assert two["n_gpus"] == 2 and two["config"]["n_ranks_seen"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["frames_per_step"] == 6000 and two["config"]["frames_per_gpu_timed"] == 3000
+    assert "one all-gather" in two["config"]["stitch"]
+    assert two["config"]["segments_out"] == one["config"]["segments_out"] > 1
+    # a range longer than the resident budget is classified in chunks, regeneration untimed
+    chunked = _bench_json(["--total-frames", "6000", "--resident-frames", "2048", "--steps", "1", "--warmup", "1",
+                           "--no-cpu-baseline"])
+    assert chunked["config"]["segments_out"] == one["config"]["segments_out"]
+    assert "intervals" in chunked["config"]["timed_region"] and one["config"]["timed_region"] == "one interval"
+
+
+def test_bench_independent_clips_shape():
+    """One clip per rank, no collective: two rank processes on this GPU."""
+    out = _bench_json(["--gpus", "2", "--independent-clips", "--clip-frames", "2500", "--steps", "1", "--warmup", "1"])
+    assert out["config"]["stitch"] == "none" and out["config"]["n_ranks_seen"] == 2
+    assert out["config"]["frames_per_step"] == 5000 and out["scaling"] == "weak"
