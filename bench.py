@@ -89,6 +89,9 @@ def parse(argv=None):
     ap.add_argument("--independent-clips", action="store_true",
                     help="multi-GPU: every rank segments its own clip (no stream gather, no collective at all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="geometries that need a real resize (not 1280x720): one fused call per batch instead of "
+                         "the resize of batch i+1 on a second stream beside the classification of batch i")
     ap.add_argument("--stage-timing", choices=["dominant", "all", "off"], default="dominant",
                     help="which kernels are bracketed with HIP events inside the timed region: the dominant "
                          "one (block 2, what the roofline object reports), every stage (each event pair costs "
@@ -337,9 +340,8 @@ def main():
                 if timed:
                     timer.start()
             a0, b0 = chunk
-            for a in range(a0, b0, bs):
-                b = min(b0, a + bs)
-                clip.classify(frames[a - a0:b - a0], a)
+            if b0 > a0:
+                clip.classify_range(frames[:b0 - a0], a0, bs, overlap=not args.no_overlap)
         if not gather:
             return clip.segment(n_local, 100, 10) if n_local else None
         return clip.segment(n_local, 100, 10, group=group, total=total)

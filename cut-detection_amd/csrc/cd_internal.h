@@ -91,7 +91,9 @@ struct cd_handle {
     int device;
     int dtype;
     cd::DeviceParams p;
-    cd::ResizeTables rt;
+    cd::ResizeTables rt;       // tables of the fused forward (cd_forward_u8 and its variants)
+    cd::ResizeTables rt_pre;   // tables of the stand-alone kernels (cd_preprocess, cd_resize_u8): a caller that
+                               // alternates a stand-alone resize with a forward on its output keeps both warm
     void* table_mem;        // one allocation behind rt.*
     void* param_mem;        // one allocation behind p.*
     float* act1;            // workspace: [frames+1][h1+2][87][48], zero border around each frame
@@ -123,6 +125,8 @@ void set_error(const char* fmt, ...);
 // kernel launchers (each queues work on `s` and returns a CD_* code)
 int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
                       int64_t frame_stride, int chan_order, float* dst, int nh, int nw, hipStream_t s);
+int launch_resize_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                     int64_t frame_stride, uint8_t* dst, int nh, int nw, hipStream_t s);
 int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s);
 int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
                     int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s);

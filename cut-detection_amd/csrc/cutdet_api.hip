@@ -218,8 +218,7 @@ void axis_tables(int src_n, int dst_n, bool zero_at_border, std::vector<int>& s,
     }
 }
 
-int ensure_tables(cd_handle* h, int H0, int W0, int nh, int nw, hipStream_t s) {
-    ResizeTables& rt = h->rt;
+int ensure_tables(ResizeTables& rt, int H0, int W0, int nh, int nw, hipStream_t s) {
     if (rt.H0 == H0 && rt.W0 == W0 && rt.h == nh && rt.w == nw) return CD_OK;
     if (H0 < 1 || W0 < 1 || nh < 1 || nw < 1 || W0 > kMaxSrcW || H0 > kMaxSrcW || nh > kMaxSrcW || nw > kMaxSrcW) {
         set_error("resize %dx%d -> %dx%d outside the supported range (1..%d per side)", W0, H0, nw, nh, kMaxSrcW);
@@ -427,12 +426,14 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);
     const size_t t_short = align_up((size_t)2 * kMaxSrcW * sizeof(short), 256);
-    CD_TRY(hipMalloc(&h->table_mem, 2 * t_int + 2 * t_short));
+    CD_TRY(hipMalloc(&h->table_mem, 2 * (2 * t_int + 2 * t_short)));
     char* t = static_cast<char*>(h->table_mem);
-    h->rt.sx = reinterpret_cast<int*>(t); t += t_int;
-    h->rt.sy = reinterpret_cast<int*>(t); t += t_int;
-    h->rt.ax = reinterpret_cast<short*>(t); t += t_short;
-    h->rt.by = reinterpret_cast<short*>(t);
+    for (ResizeTables* rt : {&h->rt, &h->rt_pre}) {
+        rt->sx = reinterpret_cast<int*>(t); t += t_int;
+        rt->sy = reinterpret_cast<int*>(t); t += t_int;
+        rt->ax = reinterpret_cast<short*>(t); t += t_short;
+        rt->by = reinterpret_cast<short*>(t); t += t_short;
+    }
     h->rle_blocks_cap = 1 << 16;   // x 4096 frames per block
     CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->rle_blocks), (size_t)h->rle_blocks_cap * sizeof(int64_t)));
 #undef CD_TRY
@@ -485,7 +486,7 @@ int cd_preprocess(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64
     if (rc) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;
+    if ((rc = ensure_tables(h->rt_pre, H0, W0, net_h, net_w, s))) return rc;
     StageTimer t(h, CD_STAGE_PREPROCESS, s);
     return launch_preprocess(h, src, n, H0, W0, row_stride, frame_stride, chan_order, dst, net_h, net_w, s);
 }
@@ -506,6 +507,18 @@ int cd_nv12_to_bgr(cd_handle* h, const uint8_t* y, const uint8_t* uv, int n, int
     DeviceGuard guard(h->device);
     return launch_nv12_to_bgr(y, uv, n, W0, y_row_stride, uv_row_stride, y_frame_stride, uv_frame_stride, y_rows,
                               uv_rows, n_rows, dst, chan_order, static_cast<hipStream_t>(stream));
+}
+
+int cd_resize_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                 int64_t frame_stride, uint8_t* dst, int net_h, int net_w, void* stream) {
+    if (!h || !dst) { set_error("cd_resize_u8: null argument"); return CD_EINVAL; }
+    int rc = check_src("cd_resize_u8", src, n, H0, W0, row_stride, frame_stride, CD_BGR);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((rc = ensure_tables(h->rt_pre, H0, W0, net_h, net_w, s))) return rc;
+    StageTimer t(h, CD_STAGE_PREPROCESS, s);
+    return launch_resize_u8(h, src, n, H0, W0, row_stride, frame_stride, dst, net_h, net_w, s);
 }
 
 int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w, float* logits, float* maxv,
@@ -533,7 +546,7 @@ int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64
     if ((rc = check_net_shape(h, n, net_h, net_w, &g))) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;
+    if ((rc = ensure_tables(h->rt, H0, W0, net_h, net_w, s))) return rc;
     if ((rc = ensure_workspace(h, n, g, s))) return rc;
     {
         StageTimer t(h, CD_STAGE_CONV1, s);
@@ -566,7 +579,7 @@ int cd_forward_u8_static(cd_handle* h, const uint8_t* src, int n, int H0, int W0
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     StaticScratch& ss = g_static[h->device];
-    if ((rc = ensure_tables(h, H0, W0, net_h, net_w, s))) return rc;
+    if ((rc = ensure_tables(h->rt, H0, W0, net_h, net_w, s))) return rc;
     if (ss.ws_h != g.h) {
         // the array keeps the previous call's contents and another height puts the borders
         // elsewhere: clear it, and finish before a later call on another stream could overtake

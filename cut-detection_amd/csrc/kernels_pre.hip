@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void preprocess_generic_kernel(
 
 int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
                       int64_t frame_stride, int chan_order, float* dst, int nh, int nw, hipStream_t s) {
-    SampleArgs a{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride, 0, 0, 0, 0, 0};
+    SampleArgs a{h->rt_pre.sx, h->rt_pre.ax, h->rt_pre.sy, h->rt_pre.by, h->rt_pre.mode, H0, W0, row_stride, 0, 0, 0, 0, 0};
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     dim3 grid((unsigned)(n * nh)), block(256);
     if (aligned) {
@@ -106,6 +106,97 @@ int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int
         hipLaunchKernelGGL(preprocess_generic_kernel, grid, block, 0, s, src, a, frame_stride, chan_order, dst,
                            nh, nw, h->p.lut);
     }
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Resize only, u8 in -> u8 out (cv2.resize at reference frameID/data.py:220-222 by itself): the same
+// row staging as preprocess_rows_kernel, the resized pixels written interleaved in the source's
+// channel order.  One workgroup per (frame, output row): at 1080p 2 x 5760 bytes in, 768 out.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_u8_rows_kernel(
+    const uint8_t* __restrict__ src, SampleArgs a, int64_t frame_stride, uint8_t* __restrict__ dst, int nh, int nw,
+    int row_bytes_padded) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t rows[];   // [2][row_bytes_padded]
+    const int tid = threadIdx.x;
+    const int y = blockIdx.x % nh;
+    const int f = blockIdx.x / nh;
+    const uint8_t* frame = src + (int64_t)f * frame_stride;
+    int r0, r1;
+    if (a.mode == 2) { r0 = 2 * y; r1 = 2 * y + 1; }
+    else {
+        int sy = a.sy[y];
+        r0 = min(max(sy, 0), a.H0 - 1);
+        r1 = min(max(sy + 1, 0), a.H0 - 1);
+    }
+    const int b0 = a.mode == 0 ? a.by[2 * y] : 0, b1 = a.mode == 0 ? a.by[2 * y + 1] : 0;
+    const bool two_rows = a.mode == 2 || (a.mode == 0 && b1 != 0);
+    const int row_bytes = a.W0 * 3;
+    const int chunks = row_bytes >> 4;
+    {
+        const uint4* g0 = reinterpret_cast<const uint4*>(frame + (int64_t)r0 * a.row_stride);
+        const uint4* g1 = reinterpret_cast<const uint4*>(frame + (int64_t)r1 * a.row_stride);
+        uint4* l0 = reinterpret_cast<uint4*>(rows);
+        uint4* l1 = reinterpret_cast<uint4*>(rows + row_bytes_padded);
+        for (int c = tid; c < chunks; c += 256) {
+            l0[c] = g0[c];
+            if (two_rows) l1[c] = g1[c];
+        }
+        for (int b = (chunks << 4) + tid; b < row_bytes; b += 256) {   // < 16 tail bytes
+            rows[b] = frame[(int64_t)r0 * a.row_stride + b];
+            if (two_rows) rows[row_bytes_padded + b] = frame[(int64_t)r1 * a.row_stride + b];
+        }
+    }
+    __syncthreads();
+    const uint8_t* R0 = rows;
+    const uint8_t* R1 = two_rows ? rows + row_bytes_padded : rows;
+    uint8_t* out = dst + ((int64_t)f * nh + y) * nw * 3;
+    for (int x = tid; x < nw; x += 256) {
+        int v[3];
+        if (a.mode == 1) {
+            int c0 = a.sx[x] * 3;
+            for (int cc = 0; cc < 3; ++cc) v[cc] = R0[c0 + cc];
+        } else if (a.mode == 2) {
+            int c0 = 6 * x;
+            for (int cc = 0; cc < 3; ++cc)
+                v[cc] = (R0[c0 + cc] + R0[c0 + 3 + cc] + R1[c0 + cc] + R1[c0 + 3 + cc] + 2) >> 2;
+        } else {
+            int c0 = a.sx[x], c1 = min(c0 + 1, a.W0 - 1);
+            int a0 = a.ax[2 * x], a1 = a.ax[2 * x + 1];
+            for (int cc = 0; cc < 3; ++cc) {
+                int S0 = R0[c0 * 3 + cc] * a0 + R0[c1 * 3 + cc] * a1;
+                int S1 = R1[c0 * 3 + cc] * a0 + R1[c1 * 3 + cc] * a1;
+                int t = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                v[cc] = min(max(t, 0), 255);
+            }
+        }
+        for (int cc = 0; cc < 3; ++cc) out[3 * x + cc] = (uint8_t)v[cc];
+    }
+}
+
+// rows that are not 16-byte aligned: taps straight from global memory
+__global__ __launch_bounds__(256) void resize_u8_generic_kernel(
+    const uint8_t* __restrict__ src, SampleArgs a, int64_t frame_stride, uint8_t* __restrict__ dst, int nh, int nw) {
+    const int y = blockIdx.x % nh;
+    const int f = blockIdx.x / nh;
+    const uint8_t* frame = src + (int64_t)f * frame_stride;
+    uint8_t* out = dst + ((int64_t)f * nh + y) * nw * 3;
+    for (int x = threadIdx.x; x < nw; x += 256)
+        for (int cc = 0; cc < 3; ++cc) out[3 * x + cc] = (uint8_t)sample_u8(frame, y, x, cc, a);
+}
+
+int launch_resize_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                     int64_t frame_stride, uint8_t* dst, int nh, int nw, hipStream_t s) {
+    SampleArgs a{h->rt_pre.sx, h->rt_pre.ax, h->rt_pre.sy, h->rt_pre.by, h->rt_pre.mode, H0, W0, row_stride, 0, 0, 0, 0, 0};
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
+    const int padded = (W0 * 3 + 15) & ~15;
+    dim3 grid((unsigned)(n * nh)), block(256);
+    if (aligned && 2 * padded <= 64 * 1024)
+        hipLaunchKernelGGL(resize_u8_rows_kernel, grid, block, (size_t)2 * padded, s, src, a, frame_stride, dst, nh, nw,
+                           padded);
+    else
+        hipLaunchKernelGGL(resize_u8_generic_kernel, grid, block, 0, s, src, a, frame_stride, dst, nh, nw);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }

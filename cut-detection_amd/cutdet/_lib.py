@@ -36,6 +36,7 @@ SIGNATURES = {
     "cd_destroy": (None, [_h]),
     "cd_reserve": (C.c_int, [_h, _i, _i]),
     "cd_preprocess": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _i, _p, _i, _i, _p]),
+    "cd_resize_u8": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _p, _i, _i, _p]),
     "cd_nv12_to_bgr": (C.c_int, [_h, _p, _p, _i, _i, _l, _l, _l, _l, _p, _p, _i, _p, _i, _p]),
     "cd_forward": (C.c_int, [_h, _p, _i, _i, _i, _p, _p, _p, _p]),
     "cd_forward_u8": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),

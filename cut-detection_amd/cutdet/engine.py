@@ -96,6 +96,21 @@ class Engine:
                                 self._stream()))
         return out
 
+    def resize_u8(self, frames, resize=NET_W, out=None):
+        """u8 [n,H0,W0,3] -> u8 [n,h,resize,3]: cv2.resize INTER_LINEAR alone (reference
+        frameID/data.py:220-222), channel order unchanged."""
+        n, H0, W0, rs, fs = self._frame_layout(frames)
+        nh, nw = output_size(H0, W0, resize)
+        if out is None:
+            out = torch.empty((n, nh, nw, 3), dtype=torch.uint8, device=self.device)
+        else:
+            self._check_dev(out, "out", torch.uint8)
+            if tuple(out.shape) != (n, nh, nw, 3) or not out.is_contiguous():
+                raise ValueError(f"out must be a contiguous u8 tensor of shape {(n, nh, nw, 3)}")
+        if n:
+            check(lib.cd_resize_u8(self._h, _ptr(frames), n, H0, W0, rs, fs, _ptr(out), nh, nw, self._stream()))
+        return out
+
     def nv12_to_bgr(self, y, uv, y_rows=None, uv_rows=None, chan_order=_lib.CD_BGR, out=None):
         """NV12 planes on the GPU - y u8 [n, Hy, W], uv u8 [n, Huv, W] (views with padded rows are
         fine) - to interleaved pixels u8 [n, rows, W, 3].  Output row r uses luma row y_rows[r] and

@@ -179,6 +179,41 @@ class ClipClassifier:
         self.engine.forward_u8(frames_u8, chan_order=chan_order,
                                out=(self.logits[sl], self.maxv[sl], self.cls[sl]))
 
+    def classify_range(self, frames_u8, offset=0, batch=256, chan_order=_lib.CD_BGR, overlap=True):
+        """Classifies frames_u8 (u8 [N,H0,W0,3] on the GPU) in batches; results land at rows
+        offset .. offset+N.  When the resize is a pure point sample (1280x720 -> 256x144) every batch
+        is one fused call.  Otherwise, with `overlap`, the resize of batch i+1 (memory-bound:
+        cd_resize_u8 on a second stream) runs beside the classification of batch i (matrix-bound:
+        cd_forward_u8 on the resized frames), handed over by events; the logits are bit-identical to
+        the fused call's."""
+        from .engine import output_size, sampled_source_rows
+        n, H0, W0 = frames_u8.shape[0], frames_u8.shape[1], frames_u8.shape[2]
+        nh, nw = output_size(H0, W0)
+        if not overlap or sampled_source_rows(H0, W0) is not None or (H0, W0) == (nh, nw):
+            for a in range(0, n, batch):
+                self.classify(frames_u8[a:a + batch], offset + a, chan_order)
+            return
+        eng, dev = self.engine, self.engine.device
+        key = (batch, nh, nw)
+        if getattr(self, "_small_key", None) != key:
+            self._small = [torch.empty((batch, nh, nw, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self._side = torch.cuda.Stream(device=dev)
+            self._ready = [torch.cuda.Event() for _ in range(2)]
+            self._free = [torch.cuda.Event() for _ in range(2)]
+            self._small_key = key
+        main = torch.cuda.current_stream(dev)
+        self._side.wait_stream(main)                 # the frames, and earlier readers of the small buffers
+        for i, a in enumerate(range(0, n, batch)):
+            b, s = min(n, a + batch), i % 2
+            with torch.cuda.stream(self._side):
+                if i >= 2:
+                    self._side.wait_event(self._free[s])
+                eng.resize_u8(frames_u8[a:b], out=self._small[s][:b - a])
+                self._ready[s].record(self._side)
+            main.wait_event(self._ready[s])
+            self.classify(self._small[s][:b - a], offset + a, chan_order)
+            self._free[s].record(main)
+
     def gathered_streams(self, n_local, group=None, total=None):
         return gather_streams(self.cls[:n_local], self.maxv[:n_local], group, total)
 

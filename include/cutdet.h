@@ -93,6 +93,18 @@ int cd_preprocess(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
                   int64_t row_stride, int64_t frame_stride, int chan_order,
                   float* dst, int net_h, int net_w, void* stream);
 
+/* The resize alone, u8 in, u8 out.
+ * Replaces cv2.resize(frame, (net_w, net_h), INTER_LINEAR) at frameID/data.py:220-222 by itself.
+ * src as in cd_preprocess; dst: device u8 [n][net_h][net_w][3], pixels interleaved in the source's
+ * channel order.  Its output fed to cd_forward_u8 (as net_h x net_w frames) gives the bits of
+ * cd_forward_u8 on the source frames: a caller with the next batch at hand can run this resize on a
+ * second stream while the previous batch is being classified (memory-bound work beside matrix-bound
+ * work), which the single fused call cannot.  Keeps its own resize tables, so alternating it with
+ * forward calls of another geometry does not re-upload anything. */
+int cd_resize_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
+                 int64_t row_stride, int64_t frame_stride,
+                 uint8_t* dst, int net_h, int net_w, void* stream);
+
 /* NV12 frames (what hardware video decoders deliver: a luma plane, then a half-height plane of
  * interleaved U,V pairs, each pair shared by a 2x2 pixel block) -> interleaved 3-byte pixels, the
  * input format of cd_preprocess / cd_forward_u8.  Stands in for the colour conversion that

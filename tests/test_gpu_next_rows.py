@@ -279,3 +279,35 @@ def test_bench_independent_clips_shape():
     out = _bench_json(["--gpus", "2", "--independent-clips", "--clip-frames", "2500", "--steps", "1", "--warmup", "1"])
     assert out["config"]["stitch"] == "none" and out["config"]["n_ranks_seen"] == 2
     assert out["config"]["frames_per_step"] == 5000 and out["scaling"] == "weak"
+
+
+# ----------------------------------------------------------------------------- stand-alone resize, overlapped pipeline
+@pytest.mark.parametrize("h,w", [(1080, 1920), (180, 320), (480, 640), (512, 512), (100, 300), (720, 1280), (90, 161)])
+def test_resize_u8_is_bit_exact(engine, h, w):
+    from oracle import preprocess, synth
+    frames = synth.clip(SEED, [0, 1, 2], h, w)
+    nh, nw = preprocess.output_size(h, w)
+    want = np.stack([preprocess.resize_linear_u8(f, nh, nw) for f in frames])
+    got = engine.resize_u8(torch.from_numpy(frames).to(engine.device)).cpu().numpy()
+    assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.parametrize("h,w,dtype", [(1080, 1920, "f32"), (180, 320, "f32"), (1080, 1920, "bf16_split"), (180, 320, "bf16")])
+def test_overlapped_resize_pipeline_matches_the_fused_call(h, w, dtype):
+    """classify_range with the resize on a second stream (three buffer reuses, a short last batch)
+    gives the bits of one fused call per batch, in every arithmetic."""
+    from cutdet import api, synth as csynth
+    from cutdet.pipeline import ClipClassifier
+    eng = api.default_engine("cuda:0", dtype)
+    n = 150
+    cl = csynth.classes_from_runs(csynth.run_table(n, SEED))
+    frames = eng.synth_frames(torch.tensor(cl, dtype=torch.uint8, device=eng.device), h, w, SEED)
+    fused, piped = ClipClassifier(eng, n), ClipClassifier(eng, n)
+    fused.classify_range(frames, 0, 32, overlap=False)
+    for _ in range(2):                                   # twice: the buffers and events are reused across calls
+        piped.logits.fill_(float("nan"))
+        piped.classify_range(frames, 0, 32)
+        torch.cuda.synchronize()
+        assert torch.equal(piped.logits, fused.logits)
+        assert torch.equal(piped.cls, fused.cls) and torch.equal(piped.maxv, fused.maxv)
+    assert fused.cls.cpu().tolist() == cl
