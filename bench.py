@@ -427,6 +427,9 @@ def main():
                 "traffic": traffic, "traffic_unit": "bytes per 256-frame launch (rocprofv3 PMC, profiles/)",
                 "launch_ms": round(conv2_ms, 4), "launches_timed": n_launch, "flops_per_frame": FLOPS_CONV2,
                 "frames_per_launch": round(frames_per_launch, 2),
+                # the kernel does not compute conv column 84 of 85, which the floor-mode pooling discards:
+                # `achieved` counts the algorithmic FLOPs, this is the rate of the MFMAs actually issued
+                "issued_frac_of_peak": round(achieved * (84.0 / 85.0) / peak_tflops, 4),
                 "whole_net_tflops": round(FLOPS_FRAME * fps / world / 1e12, 2),
                 "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps / world / 1e12 / peak_tflops, 4),
                 "hbm_compulsory_GBps": round(bytes_frame * fps / world / 1e9, 2),
