@@ -92,6 +92,10 @@ def parse(argv=None):
     ap.add_argument("--no-overlap", action="store_true",
                     help="geometries that need a real resize (not 1280x720): one fused call per batch instead of "
                          "the resize of batch i+1 on a second stream beside the classification of batch i")
+    ap.add_argument("--streams", type=int, choices=[1, 2], default=1,
+                    help="2: batches alternate between two library handles on two HIP streams, so one batch's "
+                         "kernel start-ups and tails fill with the other's work (the bracketed block-2 time then "
+                         "includes sharing the chip, so the per-kernel roofline figure is not comparable)")
     ap.add_argument("--stage-timing", choices=["dominant", "all", "off"], default="dominant",
                     help="which kernels are bracketed with HIP events inside the timed region: the dominant "
                          "one (block 2, what the roofline object reports), every stage (each event pair costs "
@@ -315,7 +319,12 @@ def main():
         fill(chunks[0])
     net_h = int(args.height * (256 / args.width))
     eng.reserve(bs, net_h)
-    clip = ClipClassifier(eng, max(n_local, 1))
+    twin = None
+    if args.streams == 2:
+        from cutdet.engine import Engine
+        twin = Engine(api.default_blob(), dev, args.dtype)
+        twin.reserve(bs, net_h)
+    clip = ClipClassifier(eng, max(n_local, 1), twin=twin)
     group = dist.group.WORLD if gather else None
     torch.cuda.synchronize()
 
@@ -358,10 +367,11 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region
-    if args.stage_timing == "dominant":
-        eng.timing_enable(True, stages=["conv2"], every=args.timing_every)
-    else:
-        eng.timing_enable(args.stage_timing == "all")
+    for e in [eng] + ([twin] if twin is not None else []):
+        if args.stage_timing == "dominant":
+            e.timing_enable(True, stages=["conv2"], every=args.timing_every)
+        else:
+            e.timing_enable(args.stage_timing == "all")
     timer.start()
     for _ in range(args.steps):
         result = one_pass(True)
@@ -369,6 +379,10 @@ def main():
     dt = timer.total
     timing = eng.timing_read()
     eng.timing_enable(False)
+    if twin is not None:
+        for k, (cnt, ms_) in twin.timing_read().items():
+            timing[k] = (timing[k][0] + cnt, timing[k][1] + ms_)
+        twin.timing_enable(False)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     seen = torch.ones((1,), dtype=torch.float64, device=t.device)
@@ -386,7 +400,7 @@ def main():
         every = args.timing_every if args.stage_timing == "dominant" else 1
         launches = [min(b0, a + bs) - a for _ in range(args.steps) for a0, b0 in chunks for a in range(a0, b0, bs)]
         sampled = launches[::every]
-        assert n_launch in (0, len(sampled)), (n_launch, len(sampled))
+        assert n_launch in (0, len(sampled)) or args.streams == 2, (n_launch, len(sampled))
         frames_per_launch = sum(sampled) / max(1, len(sampled))
         conv2_ms = ms / max(1, n_launch)
         achieved = FLOPS_CONV2 * frames_per_launch / (conv2_ms * 1e-3) / 1e12 if n_launch else 0.0
@@ -418,7 +432,7 @@ def main():
                        "n_ranks_seen": int(seen.item()),
                        "timed_region": "one interval" if timer.intervals == 1 else
                                        f"{timer.intervals} intervals: regeneration of non-resident frame chunks excluded",
-                       "resident_frames_per_rank": resident,
+                       "resident_frames_per_rank": resident, "streams": args.streams,
                        "stitch": "one all-gather of (class,max) streams over " + ("RCCL" if backend == "nccl" else backend)
                                  if group is not None else "none"},
             "roofline": {

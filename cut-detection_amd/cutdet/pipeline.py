@@ -164,8 +164,12 @@ def finish_table(initial, real_threshold=100, blank_threshold=10, keep_lone_orph
 class ClipClassifier:
     """Classifies a clip batch by batch into clip-long device buffers, then segments it."""
 
-    def __init__(self, engine, n_frames):
+    def __init__(self, engine, n_frames, twin=None):
+        """`twin`: a second Engine on the same GPU; classify_range then alternates batches between
+        the two on two streams (see _classify_two_streams)."""
         self.engine = engine
+        self.twin = twin
+        self._twin_stream = None
         self.n_frames = int(n_frames)
         dev = engine.device
         self.logits = torch.empty((self.n_frames, 3), dtype=torch.float32, device=dev)
@@ -189,6 +193,8 @@ class ClipClassifier:
         from .engine import output_size, sampled_source_rows
         n, H0, W0 = frames_u8.shape[0], frames_u8.shape[1], frames_u8.shape[2]
         nh, nw = output_size(H0, W0)
+        if self.twin is not None:
+            return self._classify_two_streams(frames_u8, offset, batch, chan_order)
         if not overlap or sampled_source_rows(H0, W0) is not None or (H0, W0) == (nh, nw):
             for a in range(0, n, batch):
                 self.classify(frames_u8[a:a + batch], offset + a, chan_order)
@@ -213,6 +219,28 @@ class ClipClassifier:
             main.wait_event(self._ready[s])
             self.classify(self._small[s][:b - a], offset + a, chan_order)
             self._free[s].record(main)
+
+    def _classify_two_streams(self, frames_u8, offset, batch, chan_order):
+        """Batches alternate between this engine on the current stream and a twin engine (its own
+        handle and activation workspace) on a second stream: the start-up and tail of one batch's
+        kernels fill with the other batch's work.  Results are complete once the current stream has
+        waited for the second one, which this does before returning."""
+        dev = self.engine.device
+        main = torch.cuda.current_stream(dev)
+        if self._twin_stream is None:
+            self._twin_stream = torch.cuda.Stream(device=dev)
+        side = self._twin_stream
+        side.wait_stream(main)
+        n = frames_u8.shape[0]
+        for i, a in enumerate(range(0, n, batch)):
+            sl = slice(offset + a, offset + min(n, a + batch))
+            out = (self.logits[sl], self.maxv[sl], self.cls[sl])
+            if i % 2 == 0:
+                self.engine.forward_u8(frames_u8[a:a + batch], chan_order=chan_order, out=out)
+            else:
+                with torch.cuda.stream(side):
+                    self.twin.forward_u8(frames_u8[a:a + batch], chan_order=chan_order, out=out)
+        main.wait_stream(side)
 
     def gathered_streams(self, n_local, group=None, total=None):
         return gather_streams(self.cls[:n_local], self.maxv[:n_local], group, total)

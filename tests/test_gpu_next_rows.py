@@ -311,3 +311,23 @@ def test_overlapped_resize_pipeline_matches_the_fused_call(h, w, dtype):
         assert torch.equal(piped.logits, fused.logits)
         assert torch.equal(piped.cls, fused.cls) and torch.equal(piped.maxv, fused.maxv)
     assert fused.cls.cpu().tolist() == cl
+
+
+def test_two_stream_batches_match_single_stream(engine):
+    """Batches alternating between two handles on two streams give the single-stream bits."""
+    from cutdet import api, synth as csynth
+    from cutdet.engine import Engine
+    from cutdet.pipeline import ClipClassifier
+    n = 700
+    cl = csynth.classes_from_runs(csynth.run_table(n, SEED))
+    frames = engine.synth_frames(torch.tensor(cl, dtype=torch.uint8, device=engine.device), 720, 1280, SEED)
+    one = ClipClassifier(engine, n)
+    one.classify_range(frames, 0, 128)
+    twin = Engine(api.default_blob(), engine.device)
+    two = ClipClassifier(engine, n, twin=twin)
+    for _ in range(2):
+        two.logits.fill_(float("nan"))
+        two.classify_range(frames, 0, 128)          # 6 batches, the last one short
+        assert torch.equal(two.logits, one.logits) and torch.equal(two.cls, one.cls)   # same stream: ordered after the join
+    assert two.segment()["csv"] == one.segment()["csv"]
+    twin.close()
