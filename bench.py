@@ -80,9 +80,10 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--height", type=int, default=H0, help="source frame height (default: the 720p headline)")
     ap.add_argument("--width", type=int, default=W0, help="source frame width")
-    ap.add_argument("--timing-every", type=int, default=1,
-                    help="with --stage-timing dominant: bracket every n-th launch of the dominant kernel "
-                         "(the roofline's launch time is the average over that sample)")
+    ap.add_argument("--timing-every", type=int, default=4,
+                    help="with --stage-timing dominant: bracket every n-th launch of the dominant kernel (an event "
+                         "pair costs about 4 us of stream time; the roofline's launch time is the average over "
+                         "that sample: 200 of the default run's 800 launches)")
     ap.add_argument("--dtype", choices=["f32", "bf16", "bf16_split"], default="f32",
                     help="f32 is the headline (the reference's arithmetic); bf16 / bf16_split run the library's "
                          "bf16 matrix-core modes - separate, non-headline measurements")
