@@ -374,7 +374,7 @@ using namespace cd;
 
 extern "C" {
 
-int cd_version(void) { return 1; }
+int cd_version(void) { return 2; }
 
 const char* cd_last_error(void) { return cd::g_err; }
 

@@ -20,12 +20,12 @@ def _declared_symbols():
 def test_library_exports_every_declared_symbol():
     from cutdet import _lib
     names = _declared_symbols()
-    assert len(names) >= 14
+    assert len(names) >= 19
     for n in names:
         assert hasattr(_lib.lib, n), f"libcutdet.so does not export {n}"
         assert n in _lib.SIGNATURES, f"no ctypes signature for {n}"
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib.cd_version() == 1
+    assert _lib.lib.cd_version() == 2
 
 
 def test_create_rejects_garbage_without_touching_the_gpu():

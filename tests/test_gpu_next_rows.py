@@ -331,3 +331,30 @@ def test_two_stream_batches_match_single_stream(engine):
         assert torch.equal(two.logits, one.logits) and torch.equal(two.cls, one.cls)   # same stream: ordered after the join
     assert two.segment()["csv"] == one.segment()["csv"]
     twin.close()
+
+
+# ----------------------------------------------------------------------------- argument checks of the newer entry points
+def test_new_entry_points_reject_bad_arguments(engine):
+    from cutdet._lib import CutdetError
+    dev = engine.device
+    y = torch.zeros((1, 8, 7), dtype=torch.uint8, device=dev)               # odd width
+    with pytest.raises(CutdetError):
+        engine.nv12_to_bgr(y, torch.zeros((1, 4, 7), dtype=torch.uint8, device=dev))
+    with pytest.raises(ValueError):
+        engine.nv12_to_bgr(torch.zeros((1, 8, 8), dtype=torch.uint8, device=dev),
+                           torch.zeros((1, 3, 8), dtype=torch.uint8, device=dev))    # chroma plane too short
+    with pytest.raises(RuntimeError):
+        engine.resize_u8(torch.zeros((1, 8, 8, 3), dtype=torch.uint8))     # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        engine.resize_u8(torch.zeros((2, 90, 160, 3), dtype=torch.uint8, device=dev),
+                         out=torch.zeros((2, 100, 256, 3), dtype=torch.uint8, device=dev))   # wrong output shape
+    logits = torch.zeros((4, 9), device=dev)
+    nine = torch.zeros((9,), dtype=torch.int64, device=dev)
+    with pytest.raises(CutdetError):                                       # more than 8 classes
+        engine.eval_accumulate(logits, torch.zeros((4,), dtype=torch.int64, device=dev), nine, nine.clone(),
+                               torch.zeros((1,), dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError):
+        engine.eval_accumulate(torch.zeros((4, 3), device=dev), torch.zeros((5,), dtype=torch.int64, device=dev),
+                               nine[:3], nine[:3].clone(), torch.zeros((1,), dtype=torch.float64, device=dev))
+    # an empty batch is a no-op for the wrappers, an error at the ABI
+    assert engine.resize_u8(torch.zeros((0, 90, 160, 3), dtype=torch.uint8, device=dev)).shape == (0, 144, 256, 3)
