@@ -409,13 +409,15 @@ def main():
         traffic = None      # measured separately under rocprofv3 --pmc; read back if the summary is present
         try:
             with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
-                traffic = json.load(f)["conv2_kernel"]["traffic_bytes"]
+                tj = json.load(f)
+            if args.dtype == "f32" and (args.height, args.width, bs) == (H0, W0, BATCH):
+                traffic = tj["conv2_kernel"]["traffic_bytes"]
+            else:
+                traffic = tj["other_configs"][f"{args.dtype}_{args.width}x{args.height}_b{bs}"]["conv2_kernel"]["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
         fps = total_frames / dt_max
         bytes_frame = compulsory_bytes(args.height, args.width, net_h)
-        if args.dtype != "f32" or (args.height, args.width) != (H0, W0):
-            traffic = None          # the committed PMC figure is of the fp32 720p kernel
         arith = {"f32": "fp32", "bf16": "bf16-matrix-core", "bf16_split": "split-bf16 (hi+lo, 4 products) matrix-core"}[args.dtype]
         out = {
             "metric": f"frames/sec classified+segmented, {args.width}x{args.height} RGB",
@@ -439,7 +441,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
                 "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
-                "traffic": traffic, "traffic_unit": "bytes per 256-frame launch (rocprofv3 PMC, profiles/)",
+                "traffic": traffic, "traffic_unit": "bytes per full-batch launch (rocprofv3 PMC, profiles/roofline_traffic.json)",
                 "launch_ms": round(conv2_ms, 4), "launches_timed": n_launch, "flops_per_frame": FLOPS_CONV2,
                 "frames_per_launch": round(frames_per_launch, 2),
                 # the kernel does not compute conv column 84 of 85, which the floor-mode pooling discards:
