@@ -8,39 +8,53 @@ Both forms work for N > 1: started without a launcher (no WORLD_SIZE in the envi
 script starts its N ranks itself as fresh child processes, before anything touches a GPU, relays
 rank 0's JSON line and exits non-zero if a rank fails.
 
-Workload: synthetic 1280x720 u8 frames resident in HBM, classified in batches of 256 frames
-(fp32) and segmented.  One STEP = one whole pass over this rank's frame range: every batch
-through the fused resize+prod_net forward, then the tail - the per-frame (class, max) streams
-are all-gathered (N > 1: the ONE collective of the job), run-length encoded on the GPU, repaired
-and merged on the host and rendered to CSV bytes.  Everything is inside the timed region.
+Headline workload: synthetic 1280x720 u8 frames resident in HBM, classified in batches of 256
+frames (fp32) and segmented.  One STEP = one whole pass over this rank's frame range: the range goes
+through the fused resize+prod_net forward (one cd_forward_u8_range call per resident chunk: batches
+alternate between two streams inside the library), then the tail - the per-frame (class, max)
+streams are all-gathered (N > 1: the ONE collective of the job), run-length encoded on the GPU,
+repaired and merged on the host and rendered to CSV bytes.  Everything is inside the timed region.
 
   default (weak scaling)    every rank owns a 10 000-frame range of an (N x 10 000)-frame game
   --total-frames T (strong) the game has T frames; rank r owns the r-th contiguous range of
                             ceil(T / N) frames (T = 200 000 on 8 GPUs is the full-game shape)
-  --independent-clips       every rank segments its own clip: no gather, no collective
+  --independent-clips       every rank segments its own clip: no gather, no collective, no process group
+
+Besides the headline the one JSON line carries, measured in the same run and outside the headline's
+timed interval:
+  roofline            the dominant kernel (block 2) bracketed with HIP events in a separate
+                      single-stream pass (one fused call per batch), so that the launch time says
+                      something about the kernel and not about what shared the chip with it
+  config4   (N = 1)   1920x1080 frames, split-bf16 matrix-core arithmetic, batch 512, with its HBM roofline
+  strong_200k (N > 1) the 200 000-frame game split into N contiguous ranges (one all-gather)
+  independent_clips (N > 1)  one 10 000-frame clip per GPU, run after the process group is gone
+  cpu_baseline (N = 1) the CPU oracle on a bounded sample of the headline clip
 
 A range that does not fit the per-rank HBM budget (--resident-frames) is classified in chunks; the
 regeneration of the next chunk's frames is then excluded from the timed region (it stands in for
-frames that would already be resident) and the JSON says so in config.timed_region.
+frames that would already be resident) and the JSON says so in timed_region.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cut-detection_amd"))
 
+from cutdet import launch  # noqa: E402  (standard library only: the parent of a self-launch never loads torch)
+
 CLIP_FRAMES = 10_000
 BATCH = 256
 H0, W0 = 720, 1280
 SEED = 1234
+GAME_FRAMES = 200_000                      # the full-game shape of the strong-scaling leg
+C4 = dict(height=1080, width=1920, batch=512, frames=4096, dtype="bf16_split")     # the 1080p bf16 configuration
 
 # algorithmic work per frame, independent of the source resolution (2 flops per MAC):
 #   block 1: 144*256 px * 48 ch * 27 ; block 2: 48*85 * 48 * 432 ; block 3: 16*28 * 48 * 432 ; FC 768*32 + 32*3
@@ -59,14 +73,14 @@ def compulsory_bytes(h0, w0, net_h):
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3                                                # dense fp32 matrix peak, MI355X
-PEAK_BF16_MFMA_TFLOPS = 2500.0                                              # dense bf16 matrix peak (--dtype bf16 only)
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                              # dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step is a whole pass over the rank's range (10 000 frames = 40 batches, ~22 ms), so a few
+    # a step is a whole pass over the rank's range (10 000 frames = 40 batches, ~21 ms), so a few
     # untimed passes are more than the ~20 ms of load the chip needs to reach its steady clocks
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -80,87 +94,24 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--height", type=int, default=H0, help="source frame height (default: the 720p headline)")
     ap.add_argument("--width", type=int, default=W0, help="source frame width")
-    ap.add_argument("--timing-every", type=int, default=4,
-                    help="with --stage-timing dominant: bracket every n-th launch of the dominant kernel (an event "
-                         "pair costs about 4 us of stream time; the roofline's launch time is the average over "
-                         "that sample: 200 of the default run's 800 launches)")
     ap.add_argument("--dtype", choices=["f32", "bf16", "bf16_split"], default="f32",
                     help="f32 is the headline (the reference's arithmetic); bf16 / bf16_split run the library's "
                          "bf16 matrix-core modes - separate, non-headline measurements")
     ap.add_argument("--independent-clips", action="store_true",
-                    help="multi-GPU: every rank segments its own clip (no stream gather, no collective at all)")
+                    help="multi-GPU: the headline itself is one clip per rank (no gather, no process group at all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="only the headline (and its roofline pass): no config4 / strong_200k / independent_clips legs")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="geometries that need a real resize (not 1280x720): one fused call per batch instead of "
-                         "the resize of batch i+1 on a second stream beside the classification of batch i")
-    ap.add_argument("--streams", type=int, choices=[1, 2], default=1,
-                    help="2: batches alternate between two library handles on two HIP streams, so one batch's "
-                         "kernel start-ups and tails fill with the other's work (the bracketed block-2 time then "
-                         "includes sharing the chip, so the per-kernel roofline figure is not comparable)")
-    ap.add_argument("--stage-timing", choices=["dominant", "all", "off"], default="dominant",
-                    help="which kernels are bracketed with HIP events inside the timed region: the dominant "
-                         "one (block 2, what the roofline object reports), every stage (each event pair costs "
-                         "a few microseconds of stream time per launch), or none")
+                    help="one fused cd_forward_u8 call per batch on one stream instead of one cd_forward_u8_range "
+                         "call per chunk (two streams inside the library, resize pass ahead where one is needed)")
+    ap.add_argument("--roofline-timing", choices=["dominant", "all"], default="dominant",
+                    help="the separate single-stream pass brackets block 2 only, or every stage")
+    ap.add_argument("--leg-steps", type=int, default=3, help="timed passes of each extra leg")
+    ap.add_argument("--leg-warmup", type=int, default=1, help="untimed passes of each extra leg")
     ap.add_argument("--cpu-sample-batches", type=int, default=40,
                     help="128-frame batches the CPU baseline times (40 = 5120 frames, about 11 s on 16 host threads)")
     return ap.parse_args(argv)
-
-
-# ---------------------------------------------------------------------------------------------
-# self-launch: python bench.py --gpus N without a launcher
-# ---------------------------------------------------------------------------------------------
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
-def spawn_ranks(n):
-    """Starts n fresh rank processes of this script (the parent never touches a GPU), relays rank
-    0's stdout, returns the job's exit code: 0 only if every rank exits 0."""
-    import threading
-    env = dict(os.environ)
-    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-
-    def relay():
-        # only the JSON line belongs on stdout; whatever else a library prints there goes to stderr
-        for line in procs[0].stdout:
-            text = line.decode("utf-8", "replace")
-            out = sys.stdout if text.lstrip().startswith("{") else sys.stderr
-            out.write(text)
-            out.flush()
-
-    reader = threading.Thread(target=relay, daemon=True)
-    reader.start()
-    failed = None
-    pending = set(range(n))
-    while pending and failed is None:
-        for r in sorted(pending):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            pending.discard(r)
-            if rc != 0:
-                failed = (r, rc)
-                break
-        time.sleep(0.05)
-    for p in procs:                      # the exact processes started above, nothing else
-        if p.poll() is None:
-            p.kill()
-        p.wait()
-    reader.join(timeout=10)
-    if failed is not None:
-        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
-        return failed[1] if failed[1] > 0 else 1
-    return 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -228,15 +179,21 @@ def rehearse_plumbing(args, world, rank):
     g_cls, g_mx = gather_streams(cls, mx, dist.group.WORLD if world > 1 else None, total)
     ok = g_cls.tolist() == classes and g_mx.shape[0] == total
     seen = torch.ones(1)
+    run_dir = [tempfile.mkdtemp(prefix="cutdet_bench_") if rank == 0 else None]
     if world > 1:
         dist.all_reduce(seen)
+        dist.broadcast_object_list(run_dir, src=0)
+        dist.barrier()
+        dist.destroy_process_group()
+    # the no-process-group rendezvous of the independent-clips leg: a file barrier and a result exchange
+    fb = launch.FileBarrier(rank, world, run_dir[0], timeout=120)
+    fb.wait()
+    texts = fb.exchange("plumbing", str(hi - lo))
     if rank == 0:
         print(json.dumps({"metric": "rehearsal: launch and stream gather only (no GPU work)", "value": None,
                           "unit": "frames/s", "n_gpus": world, "n_ranks_seen": int(seen.item()),
-                          "gathered_frames": int(g_cls.shape[0]), "gather_ok": bool(ok)}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+                          "gathered_frames": int(g_cls.shape[0]), "gather_ok": bool(ok),
+                          "file_barrier_ranks": len(texts), "file_barrier_frames": sum(int(t) for t in texts)}))
     return 0 if ok else 1
 
 
@@ -258,13 +215,210 @@ class RegionTimer:
         self.intervals += 1
 
 
+class Job:
+    """What every leg shares: the rank's place in the job, its GPU, and how ranks line up."""
+
+    def __init__(self, world, rank, dev, one_gpu, backend):
+        self.world, self.rank, self.dev, self.one_gpu, self.backend = world, rank, dev, one_gpu, backend
+        self.group = None          # the process group while one exists
+        self.files = None          # launch.FileBarrier once the process group is gone
+        self._frames = None
+
+    def frames_buffer(self, n, height, width):
+        """One u8 buffer reused by the legs (reallocated only when a leg needs a bigger one)."""
+        import torch
+        need = max(1, n) * height * width * 3
+        if self._frames is None or self._frames.numel() < need:
+            self._frames = None
+            torch.cuda.empty_cache()
+            self._frames = torch.empty((need,), dtype=torch.uint8, device=self.dev)
+        return self._frames[:need].view(max(1, n), height, width, 3)
+
+    def sync(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.world > 1:
+            if self.group is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
+            else:
+                self.files.wait()
+
+    def max_over_ranks(self, dt):
+        """(max of dt over the ranks, number of ranks that took part)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return dt, 1
+        if self.group is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+            seen = torch.ones((1,), dtype=torch.float64, device=t.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(seen)
+            return float(t.item()), int(seen.item())
+        self._tag = getattr(self, "_tag", 0) + 1
+        texts = self.files.exchange(f"dt{self._tag}", repr(dt))
+        return max(float(t) for t in texts), len(texts)
+
+
+def run_leg(job, eng, *, total, gather, steps, warmup, height, width, batch, resident_frames=None, overlap=True,
+            roofline_pass=None):
+    """One measurement: `steps` timed passes over this rank's range of a `total`-frame game after
+    `warmup` untimed ones.  gather: the ranks' streams are all-gathered and the whole game segmented
+    (needs the process group); otherwise every rank segments its own range as a clip of its own.
+    roofline_pass: None, or "dominant" / "all": afterwards, outside the timed interval, one single-stream
+    pass over the resident chunk with those stages bracketed by HIP events.
+    Returns a dict (the same on every rank where it matters: dt_max, ranks_seen)."""
+    import torch
+    from cutdet import synth as csynth
+    from cutdet.pipeline import ClipClassifier, shard_range
+    world, rank, dev = job.world, job.rank, job.dev
+    lo, hi = shard_range(total, rank, world)
+    n_local = hi - lo
+    classes_all = csynth.classes_from_runs(csynth.run_table(total, SEED))
+    frame_bytes = height * width * 3
+    # Frames a rank keeps in HBM at once.  Every rank cuts its range at the same multiples of
+    # `resident` (computed from the longest range), so that all ranks pause the timer together.
+    per = -(-total // world)
+    budget = resident_frames or int(160e9 / frame_bytes) // (world if job.one_gpu else 1)
+    resident = per if per <= budget else max(batch, budget // batch * batch)
+    chunks = [(min(n_local, a), min(n_local, a + resident)) for a in range(0, per, resident)]
+    frames = job.frames_buffer(min(resident, n_local), height, width)
+    cls_dev = torch.tensor(classes_all[lo:hi], dtype=torch.uint8, device=dev)
+
+    def fill(chunk):
+        a, b = chunk
+        if b > a:
+            eng.synth_frames(cls_dev[a:b], height, width, SEED, first_index=lo + a, out=frames[: b - a])
+
+    if chunks:
+        fill(chunks[0])
+    net_h = int(height * (256 / width))
+    eng.reserve(batch, net_h)
+    clip = ClipClassifier(eng, max(n_local, 1))
+    group = job.group if gather and world > 1 else None
+    torch.cuda.synchronize()
+    timer = RegionTimer(job.sync)
+    state = {"loaded": 0}          # index of the chunk whose frames are in `frames`
+
+    def one_pass(timed, overlapped=overlap):
+        """Classify this rank's whole range, then segment (every rank takes part in the gather;
+        rank 0's result is the job's output).  With several chunks the timer pauses while the next
+        chunk's frames are regenerated."""
+        for k, chunk in enumerate(chunks):
+            if state["loaded"] != k:
+                if timed:
+                    timer.stop()
+                fill(chunk)
+                state["loaded"] = k
+                if timed:
+                    timer.start()
+            a0, b0 = chunk
+            if b0 > a0:
+                clip.classify_range(frames[:b0 - a0], a0, batch, overlap=overlapped)
+        if group is None:
+            return clip.segment(n_local, 100, 10) if n_local else None
+        return clip.segment(n_local, 100, 10, group=group, total=total)
+
+    result = None
+    for _ in range(warmup):
+        try:
+            result = one_pass(False)
+        except IndexError:   # a range too short to hold one full-length shot
+            pass
+    torch.cuda.synchronize()
+    timer.start()
+    for _ in range(steps):
+        try:
+            result = one_pass(True)
+        except IndexError:
+            if gather or world == 1:
+                raise
+    timer.stop()
+    dt_max, seen = job.max_over_ranks(timer.total)
+    out = {"dt_max": dt_max, "ranks_seen": seen, "total": total, "n_local": n_local, "resident": resident,
+           "intervals": timer.intervals, "result": result, "net_h": net_h, "chunks": chunks,
+           "fps": total * steps / dt_max, "ms_per_step": dt_max * 1e3 / steps}
+
+    if roofline_pass:
+        # separate single-stream pass: one fused call per batch, the chosen stages bracketed by events
+        if state["loaded"] != 0 and chunks:
+            fill(chunks[0])
+            state["loaded"] = 0
+        a0, b0 = chunks[0] if chunks else (0, 0)
+        eng.timing_read()
+        if roofline_pass == "dominant":
+            eng.timing_enable(True, stages=["conv2"], every=1)
+        else:
+            eng.timing_enable(True)
+        torch.cuda.synchronize()
+        if b0 > a0:
+            for _ in range(2):
+                clip.classify_range(frames[:b0 - a0], a0, batch, overlap=False)
+        torch.cuda.synchronize()
+        out["timing"] = eng.timing_read()
+        eng.timing_enable(False)
+        out["timing_launch_frames"] = [min(b0, a + batch) - a for _ in range(2) for a in range(a0, b0, batch)]
+    return out
+
+
+def traffic_from_profiles(key):
+    """HBM bytes per full-batch launch of block 2 / per batch of the whole path, measured separately under
+    rocprofv3 --pmc and committed as profiles/roofline_traffic.json (None when the file has no such entry)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
+            tj = json.load(f)
+        node = tj
+        for k in key:
+            node = node[k]
+        return node
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def block2_roofline(leg, dtype, height, width, batch, fps_per_gpu):
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    n_launch, ms = leg["timing"]["conv2"]
+    sizes = leg["timing_launch_frames"]
+    full = [k for k in sizes if k == batch] or sizes or [batch]
+    # every launch of the pass is bracketed; partial last batches are in the average and in its frame count
+    frames_per_launch = sum(sizes) / max(1, len(sizes)) if n_launch == len(sizes) else sum(full) / len(full)
+    conv2_ms = ms / max(1, n_launch)
+    achieved = FLOPS_CONV2 * frames_per_launch / (conv2_ms * 1e-3) / 1e12 if n_launch else 0.0
+    if dtype == "f32" and (height, width, batch) == (H0, W0, BATCH):
+        traffic = traffic_from_profiles(("conv2_kernel", "traffic_bytes"))
+    else:
+        traffic = traffic_from_profiles(("other_configs", f"{dtype}_{width}x{height}_b{batch}", "conv2_kernel", "traffic_bytes"))
+    bytes_frame = compulsory_bytes(height, width, leg["net_h"])
+    return {
+        "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
+        "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "traffic": traffic, "traffic_unit": "bytes per full-batch launch (rocprofv3 PMC, profiles/roofline_traffic.json)",
+        "launch_ms": round(conv2_ms, 4), "launches_timed": n_launch, "flops_per_frame": FLOPS_CONV2,
+        "frames_per_launch": round(frames_per_launch, 2),
+        "measured_in": "a separate single-stream pass of the same run (one fused call per batch, every block-2 launch "
+                       "bracketed by HIP events on its stream), outside the interval `value` is timed over",
+        # the kernel does not compute conv column 84 of 85, which the floor-mode pooling discards:
+        # `achieved` counts the algorithmic FLOPs, this is the rate of the MFMAs actually issued
+        "issued_frac_of_peak": round(achieved * (84.0 / 85.0) / peak, 4),
+        "whole_net_tflops": round(FLOPS_FRAME * fps_per_gpu / 1e12, 2),
+        "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps_per_gpu / 1e12 / peak, 4),
+        "hbm_compulsory_GBps": round(bytes_frame * fps_per_gpu / 1e9, 2),
+        "hbm_frac_of_peak": round(bytes_frame * fps_per_gpu / 1e9 / PEAK_HBM_GBS, 5),
+    }
+
+
+def stage_table(timing):
+    return {k: {"launches": v[0], "ms_total": round(v[1], 3)} for k, v in timing.items() if v[0]}
+
+
 def main():
     args = parse()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return spawn_ranks(args.gpus)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not launch.in_rank_process() and args.gpus > 1:
+        return launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
+                                  stdout_filter=lambda text: text.lstrip().startswith("{"))
+    rank, local_rank, world = launch.rank_info()
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -282,191 +436,138 @@ def main():
         raise SystemExit(f"rank {rank}: no GPU {dev_index} on this node ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    job = Job(world, rank, dev, one_gpu, backend)
+    # The run directory of the file barrier: the launcher's (self-launch), else made by rank 0 and passed
+    # round through the process group while one exists (torch.distributed.run sets no such directory).
+    run_dir = os.environ.get("CUTDET_RUN_DIR")
+    pg_wanted = world > 1 and not args.independent_clips
+    if world > 1 and (pg_wanted or run_dir is None):
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        job.group = dist.group.WORLD
+        if run_dir is None:
+            box = [tempfile.mkdtemp(prefix="cutdet_bench_") if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            run_dir = box[0]
+        if not pg_wanted:          # only needed to agree on the directory
+            dist.barrier()
+            dist.destroy_process_group()
+            job.group = None
+    if world > 1:
+        job.files = launch.FileBarrier(rank, world, run_dir)
 
-    from cutdet import api, synth as csynth
-    from cutdet.pipeline import ClipClassifier, shard_range
+    from cutdet import api
 
     eng = api.default_engine(dev, args.dtype)
-    peak_tflops = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-    bs = args.batch
     strong = args.total_frames is not None
     total = args.total_frames if strong else world * args.clip_frames
     gather = world > 1 and not args.independent_clips
-    # this rank's contiguous frame range [lo, hi) of the total-frame game
-    lo, hi = shard_range(total, rank, world)
-    n_local = hi - lo
-    classes_all = csynth.classes_from_runs(csynth.run_table(total, SEED))
-    frame_bytes = args.height * args.width * 3
-    # Frames a rank keeps in HBM at once.  Every rank cuts its range at the same multiples of
-    # `resident` (computed from the longest range), so that all ranks pause the timer together.
-    per = -(-total // world)
-    budget = args.resident_frames or int(160e9 / frame_bytes) // (world if one_gpu else 1)
-    resident = per if per <= budget else max(bs, budget // bs * bs)
-    chunks = [(min(n_local, a), min(n_local, a + resident)) for a in range(0, per, resident)]
-    frames = torch.empty((max(1, min(resident, n_local)), args.height, args.width, 3), dtype=torch.uint8, device=dev)
-    cls_dev = torch.tensor(classes_all[lo:hi], dtype=torch.uint8, device=dev)
+    head = run_leg(job, eng, total=total, gather=gather, steps=args.steps, warmup=args.warmup, height=args.height,
+                   width=args.width, batch=args.batch, resident_frames=args.resident_frames,
+                   overlap=not args.no_overlap, roofline_pass=args.roofline_timing)
 
-    def fill(chunk):
-        a, b = chunk
-        if b > a:
-            eng.synth_frames(cls_dev[a:b], args.height, args.width, SEED, first_index=lo + a, out=frames[: b - a])
-
-    if chunks:
-        fill(chunks[0])
-    net_h = int(args.height * (256 / args.width))
-    eng.reserve(bs, net_h)
-    twin = None
-    if args.streams == 2:
-        from cutdet.engine import Engine
-        twin = Engine(api.default_blob(), dev, args.dtype)
-        twin.reserve(bs, net_h)
-    clip = ClipClassifier(eng, max(n_local, 1), twin=twin)
-    group = dist.group.WORLD if gather else None
-    torch.cuda.synchronize()
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    timer = RegionTimer(sync)
-
-    def one_pass(timed):
-        """Classify this rank's whole range, then segment (every rank takes part in the gather;
-        rank 0's result is the job's output).  With several chunks the timer pauses while the next
-        chunk's frames are regenerated."""
-        for k, chunk in enumerate(chunks):
-            if one_pass.loaded != k:
-                if timed:
-                    timer.stop()
-                fill(chunk)
-                one_pass.loaded = k
-                if timed:
-                    timer.start()
-            a0, b0 = chunk
-            if b0 > a0:
-                clip.classify_range(frames[:b0 - a0], a0, bs, overlap=not args.no_overlap)
-        if not gather:
-            return clip.segment(n_local, 100, 10) if n_local else None
-        return clip.segment(n_local, 100, 10, group=group, total=total)
-
-    one_pass.loaded = 0          # index of the chunk whose frames are in `frames`
-
-    # ---- warm-up (untimed): W whole passes, so RCCL and every kernel are initialised
-    result = None
-    for _ in range(args.warmup):
-        try:
-            result = one_pass(False)
-        except IndexError:   # a range too short to hold one full-length shot
-            pass
-    torch.cuda.synchronize()
-
-    # ---- timed region
-    for e in [eng] + ([twin] if twin is not None else []):
-        if args.stage_timing == "dominant":
-            e.timing_enable(True, stages=["conv2"], every=args.timing_every)
-        else:
-            e.timing_enable(args.stage_timing == "all")
-    timer.start()
-    for _ in range(args.steps):
-        result = one_pass(True)
-    timer.stop()
-    dt = timer.total
-    timing = eng.timing_read()
-    eng.timing_enable(False)
-    if twin is not None:
-        for k, (cnt, ms_) in twin.timing_read().items():
-            timing[k] = (timing[k][0] + cnt, timing[k][1] + ms_)
-        twin.timing_enable(False)
-
-    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    seen = torch.ones((1,), dtype=torch.float64, device=t.device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(seen)
-    dt_max = float(t.item())
-    frames_per_step = total
-    total_frames = frames_per_step * args.steps
+    extra = {}
+    cpu_sample = None
+    if world == 1 and not args.no_cpu_baseline:
+        nb = max(1, min(args.cpu_sample_batches, min(head["resident"], head["n_local"]) // 128 - 2))
+        a0, b0 = head["chunks"][0]
+        cpu_sample = job.frames_buffer(b0 - a0, args.height, args.width)[: (2 + nb) * 128].cpu()   # chunk 0 is loaded
+    default_run = (args.dtype, args.height, args.width, args.batch) == ("f32", H0, W0, BATCH) and not strong \
+        and not args.independent_clips and not args.no_extra_legs
+    if default_run and world == 1:
+        # ---- configuration 4: 1920x1080, split-bf16 matrix cores, batch 512
+        eng4 = api.default_engine(dev, C4["dtype"])
+        leg = run_leg(job, eng4, total=C4["frames"], gather=False, steps=args.leg_steps + 2, warmup=args.leg_warmup + 1,
+                      height=C4["height"], width=C4["width"], batch=C4["batch"], roofline_pass="all")
+        bytes_frame = compulsory_bytes(C4["height"], C4["width"], leg["net_h"])
+        gbs = bytes_frame * leg["fps"] / 1e9
+        key = f"{C4['dtype']}_{C4['width']}x{C4['height']}_b{C4['batch']}"
+        extra["config4"] = {
+            "value": round(leg["fps"], 1), "unit": "frames/s", "ms_per_step": round(leg["ms_per_step"], 4),
+            "steps": args.leg_steps + 2, "warmup": args.leg_warmup + 1, "dtype": "bf16 (split: hi+lo bfloat16 operands, "
+            "fp32 accumulate; logits within 1e-3 of fp32)",
+            "workload": f"{C4['frames']} synthetic {C4['width']}x{C4['height']} u8 frames resident in HBM, batch={C4['batch']}, "
+                        "resize pass on a third stream one batch ahead + classify on two alternating streams, GPU "
+                        "run-length encode, host glue/merge, CSV; one step = one pass over the clip",
+            "roofline": {"bound": "hbm", "kernel": "whole path (resize + blocks 1-3 per 512-frame batch)",
+                         "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "algorithmic_bytes_per_frame": bytes_frame,
+                         "traffic": traffic_from_profiles(("other_configs", key, "path", "traffic_bytes")),
+                         "traffic_unit": "HBM bytes per 512-frame batch over all kernels of the path (rocprofv3 PMC, "
+                                         "profiles/roofline_traffic.json)",
+                         "whole_net_frac_of_bf16_mfma_peak": round(FLOPS_FRAME * leg["fps"] / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)},
+            "stages_single_stream_pass": stage_table(leg["timing"]),
+            "segments_out": int(len(leg["result"]["merged"]["start_frames"])),
+        }
+    if default_run and world > 1:
+        # ---- configuration 3: the full game, strong-scaled over the ranks, one all-gather
+        leg = run_leg(job, eng, total=GAME_FRAMES, gather=True, steps=args.leg_steps, warmup=args.leg_warmup,
+                      height=H0, width=W0, batch=BATCH, resident_frames=args.resident_frames)
+        extra["strong_200k"] = {
+            "value": round(leg["fps"], 1), "unit": "frames/s", "ms_per_step": round(leg["ms_per_step"], 4),
+            "n_ranks_seen": leg["ranks_seen"], "scaling": "strong", "steps": args.leg_steps, "warmup": args.leg_warmup,
+            "frames_per_step": GAME_FRAMES, "frames_per_rank": leg["n_local"], "resident_frames_per_rank": leg["resident"],
+            "timed_region": "one interval" if leg["intervals"] == 1 else
+                            f"{leg['intervals']} intervals: regeneration of non-resident frame chunks excluded",
+            "stitch": "one all-gather of (class,max) streams over " + ("RCCL" if backend == "nccl" else backend),
+            "segments_out": int(len(leg["result"]["merged"]["start_frames"])) if leg["result"] else None,
+        }
+    if job.group is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        job.group = None
+    if default_run and world > 1:
+        # ---- configuration 5: one clip per GPU; the process group is gone, ranks line up through files
+        assert not dist.is_initialized()
+        leg = run_leg(job, eng, total=world * CLIP_FRAMES, gather=False, steps=args.leg_steps, warmup=args.leg_warmup,
+                      height=H0, width=W0, batch=BATCH, resident_frames=args.resident_frames)
+        extra["independent_clips"] = {
+            "value": round(leg["fps"], 1), "unit": "frames/s", "ms_per_step": round(leg["ms_per_step"], 4),
+            "n_ranks_seen": leg["ranks_seen"], "scaling": "weak", "steps": args.leg_steps, "warmup": args.leg_warmup,
+            "frames_per_step": world * CLIP_FRAMES, "clips": world, "process_group": "none",
+            "rendezvous": "file barrier (no collective, no network)",
+            "segments_out_rank0": int(len(leg["result"]["merged"]["start_frames"])) if leg["result"] else None,
+        }
 
     if rank == 0:
-        merged = result["merged"]
-        n_launch, ms = timing["conv2"]
-        # the bracketed launches: every batch of every timed pass, or every timing_every-th one
-        every = args.timing_every if args.stage_timing == "dominant" else 1
-        launches = [min(b0, a + bs) - a for _ in range(args.steps) for a0, b0 in chunks for a in range(a0, b0, bs)]
-        sampled = launches[::every]
-        assert n_launch in (0, len(sampled)) or args.streams == 2, (n_launch, len(sampled))
-        frames_per_launch = sum(sampled) / max(1, len(sampled))
-        conv2_ms = ms / max(1, n_launch)
-        achieved = FLOPS_CONV2 * frames_per_launch / (conv2_ms * 1e-3) / 1e12 if n_launch else 0.0
-        stages = {k: {"launches": v[0], "ms_total": round(v[1], 3)} for k, v in timing.items() if v[0]}
-        traffic = None      # measured separately under rocprofv3 --pmc; read back if the summary is present
-        try:
-            with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
-                tj = json.load(f)
-            if args.dtype == "f32" and (args.height, args.width, bs) == (H0, W0, BATCH):
-                traffic = tj["conv2_kernel"]["traffic_bytes"]
-            else:
-                traffic = tj["other_configs"][f"{args.dtype}_{args.width}x{args.height}_b{bs}"]["conv2_kernel"]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
-        fps = total_frames / dt_max
-        bytes_frame = compulsory_bytes(args.height, args.width, net_h)
+        fps = head["fps"]
+        merged = head["result"]["merged"]
+        net_h = head["net_h"]
         arith = {"f32": "fp32", "bf16": "bf16-matrix-core", "bf16_split": "split-bf16 (hi+lo, 4 products) matrix-core"}[args.dtype]
         out = {
             "metric": f"frames/sec classified+segmented, {args.width}x{args.height} RGB",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt_max * 1e3 / args.steps, 4),
+            "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"{total}-frame synthetic {args.width}x{args.height} u8 game split into {world} contiguous "
                                     f"range(s)" if strong else
                                     f"{args.clip_frames} synthetic {args.width}x{args.height} u8 frames per GPU") +
-                                   f" resident in HBM, batch={bs}, {arith} prod_net, fused resize+classify, GPU run-length "
+                                   f" resident in HBM, batch={args.batch}, {arith} prod_net, fused resize+classify, GPU run-length "
                                    f"encode, host glue/merge, CSV; one step = one pass over the range(s)",
-                       "frames_per_step": frames_per_step, "frames_per_gpu_timed": n_local * args.steps,
+                       "frames_per_step": total, "frames_per_gpu_timed": head["n_local"] * args.steps,
                        "segments_out": int(len(merged["start_frames"])),
-                       "n_ranks_seen": int(seen.item()),
-                       "timed_region": "one interval" if timer.intervals == 1 else
-                                       f"{timer.intervals} intervals: regeneration of non-resident frame chunks excluded",
-                       "resident_frames_per_rank": resident, "streams": args.streams,
+                       "n_ranks_seen": head["ranks_seen"],
+                       "timed_region": "one interval" if head["intervals"] == 1 else
+                                       f"{head['intervals']} intervals: regeneration of non-resident frame chunks excluded",
+                       "resident_frames_per_rank": head["resident"],
+                       "streams": "one fused call per batch on one stream" if args.no_overlap else
+                                  "one cd_forward_u8_range call per chunk: batches alternate between two streams inside the library",
                        "stitch": "one all-gather of (class,max) streams over " + ("RCCL" if backend == "nccl" else backend)
-                                 if group is not None else "none"},
-            "roofline": {
-                "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
-                "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(achieved / peak_tflops, 4),
-                "traffic": traffic, "traffic_unit": "bytes per full-batch launch (rocprofv3 PMC, profiles/roofline_traffic.json)",
-                "launch_ms": round(conv2_ms, 4), "launches_timed": n_launch, "flops_per_frame": FLOPS_CONV2,
-                "frames_per_launch": round(frames_per_launch, 2),
-                # the kernel does not compute conv column 84 of 85, which the floor-mode pooling discards:
-                # `achieved` counts the algorithmic FLOPs, this is the rate of the MFMAs actually issued
-                "issued_frac_of_peak": round(achieved * (84.0 / 85.0) / peak_tflops, 4),
-                "whole_net_tflops": round(FLOPS_FRAME * fps / world / 1e12, 2),
-                "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps / world / 1e12 / peak_tflops, 4),
-                "hbm_compulsory_GBps": round(bytes_frame * fps / world / 1e9, 2),
-                "hbm_frac_of_peak": round(bytes_frame * fps / world / 1e9 / PEAK_HBM_GBS, 5),
-            },
-            "stages": stages,
+                                 if gather else "none",
+                       "process_group": ("RCCL" if backend == "nccl" else backend) if pg_wanted else "none"},
+            "roofline": block2_roofline(head, args.dtype, args.height, args.width, args.batch, fps / world),
+            "stages": stage_table(head["timing"]),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            nb = args.cpu_sample_batches
-            if one_pass.loaded != 0:
-                fill(chunks[0])
-            nb = max(1, min(nb, min(resident, n_local) // 128 - 2))
-            sample = frames[: (2 + nb) * 128].cpu()
-            out["cpu_baseline"] = cpu_baseline(sample, 2, nb)
+        out.update(extra)
+        if cpu_sample is not None:
+            nb = cpu_sample.shape[0] // 128 - 2
+            out["cpu_baseline"] = cpu_baseline(cpu_sample, 2, nb)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     return 0
 
 

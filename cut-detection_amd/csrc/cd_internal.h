@@ -87,6 +87,13 @@ struct DeviceParams {
 
 }  // namespace cd
 
+namespace cd {
+struct Workspace {
+    float* act1;            // [frames+1][h1+2][87][48], zero border around each frame
+    float* act2;            // [frames+1][h2+2][30][48], zero border around each frame
+};
+}  // namespace cd
+
 struct cd_handle {
     int device;
     int dtype;
@@ -94,12 +101,21 @@ struct cd_handle {
     cd::ResizeTables rt;       // tables of the fused forward (cd_forward_u8 and its variants)
     cd::ResizeTables rt_pre;   // tables of the stand-alone kernels (cd_preprocess, cd_resize_u8): a caller that
                                // alternates a stand-alone resize with a forward on its output keeps both warm
+    cd::ResizeTables rt_id;    // tables of the forward on frames that are already net_h x 256 (the second half
+                               // of cd_forward_u8_range's resize-then-classify pipeline)
     void* table_mem;        // one allocation behind rt.*
     void* param_mem;        // one allocation behind p.*
-    float* act1;            // workspace: [frames+1][h1+2][87][48], zero border around each frame
-    float* act2;            // workspace: [frames+1][h2+2][30][48], zero border around each frame
-    size_t act1_bytes, act2_bytes;
-    int ws_h;               // network input height the borders are laid out for
+    // Activation workspaces.  ws[0] serves the single-batch entry points; cd_forward_u8_range alternates
+    // batches between ws[0] on the caller's stream and ws[1] on a stream of its own.
+    cd::Workspace ws[2];
+    size_t act1_bytes[2], act2_bytes[2];
+    int ws_h[2];            // network input height each workspace's borders are laid out for
+    // cd_forward_u8_range: side streams (classification of every other batch; stand-alone resize) and
+    // the events that fork from / join into the caller's stream and hand resized batches over
+    hipStream_t side_cls, side_pre;
+    hipEvent_t ev_fork, ev_join, ev_ready[3], ev_free[3];
+    uint8_t* small;         // resized frames of up to three batches in flight: [3][small_frames][net_h][256][3]
+    size_t small_bytes;     // bytes of one of the three slots
     int64_t* rle_blocks;    // workspace of cd_rle: per-block boundary counts / offsets
     int rle_blocks_cap;
     // optional per-stage timing: HIP event pairs recorded around each stage's launches
@@ -127,12 +143,13 @@ int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int
                       int64_t frame_stride, int chan_order, float* dst, int nh, int nw, hipStream_t s);
 int launch_resize_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
                      int64_t frame_stride, uint8_t* dst, int nh, int nw, hipStream_t s);
-int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s);
-int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
-                    int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s);
-int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s);
+// (the forward kernels read and write the activation buffers of `ws`; `rt` holds the resize tables)
+int launch_conv1_f32(const cd_handle* h, const Workspace& ws, const float* x, int n, const Geometry& g, hipStream_t s);
+int launch_conv1_u8(const cd_handle* h, const Workspace& ws, const ResizeTables& rt, const uint8_t* src, int n, int H0,
+                    int W0, int64_t row_stride, int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s);
+int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s);
 int init_conv3_head();
-int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logits, float* maxv,
+int launch_conv3_head(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, float* logits, float* maxv,
                       int64_t* argmax, hipStream_t s);
 int launch_rle(const cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset,
                int64_t* end, int64_t* type, int64_t* runlen, int64_t* start, float* mean, double* sum,

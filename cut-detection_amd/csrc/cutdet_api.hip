@@ -258,31 +258,33 @@ int ensure_tables(ResizeTables& rt, int H0, int W0, int nh, int nw, hipStream_t 
 // Activations are stored with a one-pixel zero border per frame, plus one frame of slack at the
 // end so that clamped reads of partial tiles stay inside the allocation.  The whole buffer is
 // zeroed once here; the kernels only ever write interior cells, so the border stays zero.
-int ensure_workspace(cd_handle* h, int n, const Geometry& g, hipStream_t s) {
+int ensure_workspace(cd_handle* h, int k, int n, const Geometry& g, hipStream_t s) {
     const size_t need1 = (size_t)(n + 1) * (g.h1 + 2) * (kW1 + 2) * kC * sizeof(float);
     const size_t need2 = (size_t)(n + 1) * (g.h2 + 2) * (kW2 + 2) * kC * sizeof(float);
-    const bool same_shape = h->ws_h == g.h;
-    if (same_shape && need1 <= h->act1_bytes && need2 <= h->act2_bytes) return CD_OK;
+    Workspace& w = h->ws[k];
+    const bool same_shape = h->ws_h[k] == g.h;
+    if (same_shape && need1 <= h->act1_bytes[k] && need2 <= h->act2_bytes[k]) return CD_OK;
     CD_HIP(hipStreamSynchronize(s));
-    if (need1 > h->act1_bytes) {
-        if (h->act1) CD_HIP(hipFree(h->act1));
-        h->act1 = nullptr; h->act1_bytes = 0;
-        CD_HIP(hipMalloc(reinterpret_cast<void**>(&h->act1), need1));
-        h->act1_bytes = need1;
+    if (k == 1 && h->side_cls) CD_HIP(hipStreamSynchronize(h->side_cls));   // the stream that last used ws[1]
+    if (need1 > h->act1_bytes[k]) {
+        if (w.act1) CD_HIP(hipFree(w.act1));
+        w.act1 = nullptr; h->act1_bytes[k] = 0;
+        CD_HIP(hipMalloc(reinterpret_cast<void**>(&w.act1), need1));
+        h->act1_bytes[k] = need1;
     }
-    if (need2 > h->act2_bytes) {
-        if (h->act2) CD_HIP(hipFree(h->act2));
-        h->act2 = nullptr; h->act2_bytes = 0;
-        CD_HIP(hipMalloc(reinterpret_cast<void**>(&h->act2), need2));
-        h->act2_bytes = need2;
+    if (need2 > h->act2_bytes[k]) {
+        if (w.act2) CD_HIP(hipFree(w.act2));
+        w.act2 = nullptr; h->act2_bytes[k] = 0;
+        CD_HIP(hipMalloc(reinterpret_cast<void**>(&w.act2), need2));
+        h->act2_bytes[k] = need2;
     }
     // a different input height moves the borders: re-zero everything
-    CD_HIP(hipMemsetAsync(h->act1, 0, h->act1_bytes, s));
-    CD_HIP(hipMemsetAsync(h->act2, 0, h->act2_bytes, s));
+    CD_HIP(hipMemsetAsync(w.act1, 0, h->act1_bytes[k], s));
+    CD_HIP(hipMemsetAsync(w.act2, 0, h->act2_bytes[k], s));
     // The zeroing is complete before this returns: the next call may come on another stream, which
     // nothing would order behind a memset still queued on this one.
     CD_HIP(hipStreamSynchronize(s));
-    h->ws_h = g.h;
+    h->ws_h[k] = g.h;
     return CD_OK;
 }
 
@@ -294,6 +296,7 @@ constexpr int kMaxDevices = 64;
 struct StaticScratch {
     unsigned char* ptr = nullptr;   // device address of `scratch` on this GPU
     int ws_h = 0;                   // network input height its zero borders are laid out for
+    int ws_es = 0;                  // ... and the activation element size (2: bf16 cells, 4: fp32 / split bf16)
 };
 StaticScratch g_static[kMaxDevices];
 std::mutex g_static_mutex;
@@ -357,6 +360,59 @@ struct StageTimer {
     }
 };
 
+// The three kernels of one batch on stream s, activations in `ws`, resize tables `rt` (already on the
+// device for this geometry).  `timed`: bracket the stages with events when the handle's timing is on.
+int forward_u8_on(cd_handle* h, const Workspace& ws, const ResizeTables& rt, const uint8_t* src, int n, int H0, int W0,
+                  int64_t row_stride, int64_t frame_stride, int chan_order, const Geometry& g, float* logits, float* maxv,
+                  int64_t* argmax, hipStream_t s, bool timed) {
+    int rc;
+    if (!timed) {
+        if ((rc = launch_conv1_u8(h, ws, rt, src, n, H0, W0, row_stride, frame_stride, chan_order, g, s))) return rc;
+        if ((rc = launch_conv2(h, ws, n, g, s))) return rc;
+        return launch_conv3_head(h, ws, n, g, logits, maxv, argmax, s);
+    }
+    {
+        StageTimer t(h, CD_STAGE_CONV1, s);
+        if ((rc = launch_conv1_u8(h, ws, rt, src, n, H0, W0, row_stride, frame_stride, chan_order, g, s))) return rc;
+    }
+    { StageTimer t(h, CD_STAGE_CONV2, s); if ((rc = launch_conv2(h, ws, n, g, s))) return rc; }
+    StageTimer t(h, CD_STAGE_CONV3_HEAD, s);
+    return launch_conv3_head(h, ws, n, g, logits, maxv, argmax, s);
+}
+
+// Whether the resize H0 x W0 -> nh x nw is a pure point sample (every tap weight 0 or 1 and in range):
+// then the fused first block gathers single source pixels and a separate resize pass gains nothing.
+bool resize_is_point_sample(int H0, int W0, int nh, int nw) {
+    std::vector<int> sx, sy;
+    std::vector<short> ax, by;
+    axis_tables(W0, nw, true, sx, ax);
+    axis_tables(H0, nh, false, sy, by);
+    if (H0 == 2 * nh && W0 == 2 * nw) return false;
+    bool point = true;
+    for (int x = 0; x < nw; ++x) point &= ax[2 * x + 1] == 0 && ax[2 * x] == 2048;
+    for (int y = 0; y < nh; ++y) point &= by[2 * y + 1] == 0 && by[2 * y] == 2048 && sy[y] >= 0 && sy[y] < H0;
+    return point;
+}
+
+// Streams and events of cd_forward_u8_range, created on first use (with the handle's device current).
+int ensure_range_state(cd_handle* h) {
+    if (h->side_cls) return CD_OK;
+    hipStream_t a = nullptr, b = nullptr;
+    CD_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipStreamDestroy(a);
+        set_error("cd_forward_u8_range: cannot create a stream");
+        return CD_EHIP;
+    }
+    hipEvent_t* ev[8] = {&h->ev_fork, &h->ev_join, &h->ev_ready[0], &h->ev_ready[1], &h->ev_ready[2],
+                         &h->ev_free[0], &h->ev_free[1], &h->ev_free[2]};
+    for (hipEvent_t* e : ev)
+        if (!*e) CD_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    h->side_pre = b;
+    h->side_cls = a;
+    return CD_OK;
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -374,7 +430,7 @@ using namespace cd;
 
 extern "C" {
 
-int cd_version(void) { return 2; }
+int cd_version(void) { return 3; }
 
 const char* cd_last_error(void) { return cd::g_err; }
 
@@ -426,9 +482,9 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);
     const size_t t_short = align_up((size_t)2 * kMaxSrcW * sizeof(short), 256);
-    CD_TRY(hipMalloc(&h->table_mem, 2 * (2 * t_int + 2 * t_short)));
+    CD_TRY(hipMalloc(&h->table_mem, 3 * (2 * t_int + 2 * t_short)));
     char* t = static_cast<char*>(h->table_mem);
-    for (ResizeTables* rt : {&h->rt, &h->rt_pre}) {
+    for (ResizeTables* rt : {&h->rt, &h->rt_pre, &h->rt_id}) {
         rt->sx = reinterpret_cast<int*>(t); t += t_int;
         rt->sy = reinterpret_cast<int*>(t); t += t_int;
         rt->ax = reinterpret_cast<short*>(t); t += t_short;
@@ -448,8 +504,16 @@ void cd_destroy(cd_handle* h) {
     DeviceGuard guard(h->device);
     if (h->param_mem) (void)hipFree(h->param_mem);
     if (h->table_mem) (void)hipFree(h->table_mem);
-    if (h->act1) (void)hipFree(h->act1);
-    if (h->act2) (void)hipFree(h->act2);
+    for (int k = 0; k < 2; ++k) {
+        if (h->ws[k].act1) (void)hipFree(h->ws[k].act1);
+        if (h->ws[k].act2) (void)hipFree(h->ws[k].act2);
+    }
+    if (h->small) (void)hipFree(h->small);
+    if (h->side_cls) (void)hipStreamDestroy(h->side_cls);
+    if (h->side_pre) (void)hipStreamDestroy(h->side_pre);
+    for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_ready[0], h->ev_ready[1], h->ev_ready[2], h->ev_free[0],
+                         h->ev_free[1], h->ev_free[2]})
+        if (e) (void)hipEventDestroy(e);
     if (h->rle_blocks) (void)hipFree(h->rle_blocks);
     for (int st = 0; st < CD_STAGE_COUNT; ++st) {
         for (hipEvent_t e : h->ev_start[st]) (void)hipEventDestroy(e);
@@ -464,7 +528,7 @@ int cd_reserve(cd_handle* h, int max_frames, int net_h) {
     int rc = check_net_shape(h, max_frames, net_h, kNetW, &g);
     if (rc) return rc;
     DeviceGuard guard(h->device);
-    return ensure_workspace(h, max_frames, g, nullptr);
+    return ensure_workspace(h, 0, max_frames, g, nullptr);
 }
 
 static int check_src(const char* who, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
@@ -529,11 +593,11 @@ int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w, float*
     if (rc) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = ensure_workspace(h, n, g, s))) return rc;
-    { StageTimer t(h, CD_STAGE_CONV1, s); if ((rc = launch_conv1_f32(h, x, n, g, s))) return rc; }
-    { StageTimer t(h, CD_STAGE_CONV2, s); if ((rc = launch_conv2(h, n, g, s))) return rc; }
+    if ((rc = ensure_workspace(h, 0, n, g, s))) return rc;
+    { StageTimer t(h, CD_STAGE_CONV1, s); if ((rc = launch_conv1_f32(h, h->ws[0], x, n, g, s))) return rc; }
+    { StageTimer t(h, CD_STAGE_CONV2, s); if ((rc = launch_conv2(h, h->ws[0], n, g, s))) return rc; }
     StageTimer t(h, CD_STAGE_CONV3_HEAD, s);
-    return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
+    return launch_conv3_head(h, h->ws[0], n, g, logits, maxv, argmax, s);
 }
 
 int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
@@ -547,14 +611,9 @@ int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((rc = ensure_tables(h->rt, H0, W0, net_h, net_w, s))) return rc;
-    if ((rc = ensure_workspace(h, n, g, s))) return rc;
-    {
-        StageTimer t(h, CD_STAGE_CONV1, s);
-        if ((rc = launch_conv1_u8(h, src, n, H0, W0, row_stride, frame_stride, chan_order, g, s))) return rc;
-    }
-    { StageTimer t(h, CD_STAGE_CONV2, s); if ((rc = launch_conv2(h, n, g, s))) return rc; }
-    StageTimer t(h, CD_STAGE_CONV3_HEAD, s);
-    return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
+    if ((rc = ensure_workspace(h, 0, n, g, s))) return rc;
+    return forward_u8_on(h, h->ws[0], h->rt, src, n, H0, W0, row_stride, frame_stride, chan_order, g, logits, maxv,
+                         argmax, s, true);
 }
 
 int cd_forward_u8_static(cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
@@ -580,25 +639,102 @@ int cd_forward_u8_static(cd_handle* h, const uint8_t* src, int n, int H0, int W0
     hipStream_t s = static_cast<hipStream_t>(stream);
     StaticScratch& ss = g_static[h->device];
     if ((rc = ensure_tables(h->rt, H0, W0, net_h, net_w, s))) return rc;
-    if (ss.ws_h != g.h) {
-        // the array keeps the previous call's contents and another height puts the borders
-        // elsewhere: clear it, and finish before a later call on another stream could overtake
-        CD_HIP(hipMemsetAsync(ss.ptr, 0, kStaticScratchBytes, s));
-        CD_HIP(hipStreamSynchronize(s));
-        ss.ws_h = g.h;
-    }
-    // the kernels take the activation buffers from the handle: lend it the array for this call
-    struct Lend {
-        cd_handle* h; float *a1, *a2;
-        Lend(cd_handle* h_, unsigned char* p, size_t off2) : h(h_), a1(h_->act1), a2(h_->act2) {
-            h->act1 = reinterpret_cast<float*>(p);
-            h->act2 = reinterpret_cast<float*>(p + off2);
+    {
+        // The array keeps the previous call's contents.  Another input height, or another element
+        // size over the same [rows][cols][48] cells (bf16 handles store 2-byte cells, fp32 and split
+        // bf16 handles 4-byte ones), puts the zero borders elsewhere: clear it, and finish before a
+        // later call on another stream could overtake.
+        const int es = h->dtype == CD_BF16 ? 2 : 4;
+        std::lock_guard<std::mutex> lock(g_static_mutex);
+        if (ss.ws_h != g.h || ss.ws_es != es) {
+            CD_HIP(hipMemsetAsync(ss.ptr, 0, kStaticScratchBytes, s));
+            CD_HIP(hipStreamSynchronize(s));
+            ss.ws_h = g.h;
+            ss.ws_es = es;
         }
-        ~Lend() { h->act1 = a1; h->act2 = a2; }
-    } lend(h, ss.ptr, lay.act2_off);
-    if ((rc = launch_conv1_u8(h, src, n, H0, W0, row_stride, frame_stride, chan_order, g, s))) return rc;
-    if ((rc = launch_conv2(h, n, g, s))) return rc;
-    return launch_conv3_head(h, n, g, logits, maxv, argmax, s);
+    }
+    const Workspace ws{reinterpret_cast<float*>(ss.ptr), reinterpret_cast<float*>(ss.ptr + lay.act2_off)};
+    return forward_u8_on(h, ws, h->rt, src, n, H0, W0, row_stride, frame_stride, chan_order, g, logits, maxv, argmax, s,
+                         false);
+}
+
+int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, int H0, int W0, int64_t row_stride,
+                        int64_t frame_stride, int chan_order, int net_h, int net_w, float* logits, float* maxv,
+                        int64_t* argmax, void* stream) {
+    if (!h || !logits) { set_error("cd_forward_u8_range: null argument"); return CD_EINVAL; }
+    if (n < 1 || batch < 1) { set_error("cd_forward_u8_range: %lld frames in batches of %d", (long long)n, batch); return CD_EINVAL; }
+    const int first = (int)std::min<int64_t>(n, batch);
+    int rc = check_src("cd_forward_u8_range", src, first, H0, W0, row_stride, frame_stride, chan_order);
+    if (rc) return rc;
+    Geometry g;
+    if ((rc = check_net_shape(h, first, net_h, net_w, &g))) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t nb = (n + batch - 1) / batch;
+    if (nb == 1) {       // one batch: exactly cd_forward_u8
+        if ((rc = ensure_tables(h->rt, H0, W0, net_h, net_w, s))) return rc;
+        if ((rc = ensure_workspace(h, 0, first, g, s))) return rc;
+        return forward_u8_on(h, h->ws[0], h->rt, src, first, H0, W0, row_stride, frame_stride, chan_order, g, logits,
+                             maxv, argmax, s, true);
+    }
+    // A geometry that needs a real resize goes through a stand-alone resize pass one batch ahead
+    // (memory-bound) beside the classification of resized frames (matrix-bound); a point-sampling
+    // geometry, and frames that already have the network's size, go straight into the fused block 1.
+    const bool two_pass = !(H0 == net_h && W0 == net_w) && !resize_is_point_sample(H0, W0, net_h, net_w);
+    if ((rc = ensure_range_state(h))) return rc;
+    const ResizeTables* rt = &h->rt;
+    if (two_pass) {
+        if ((rc = ensure_tables(h->rt_pre, H0, W0, net_h, net_w, s))) return rc;
+        if ((rc = ensure_tables(h->rt_id, net_h, net_w, net_h, net_w, s))) return rc;
+        rt = &h->rt_id;
+        const size_t slot = (size_t)batch * net_h * net_w * 3;
+        if (slot > h->small_bytes) {
+            CD_HIP(hipStreamSynchronize(s));
+            CD_HIP(hipStreamSynchronize(h->side_cls));
+            CD_HIP(hipStreamSynchronize(h->side_pre));
+            if (h->small) CD_HIP(hipFree(h->small));
+            h->small = nullptr; h->small_bytes = 0;
+            CD_HIP(hipMalloc(reinterpret_cast<void**>(&h->small), 3 * slot + 16));   // + the 16-byte row-tail slack
+            h->small_bytes = slot;
+        }
+    } else if ((rc = ensure_tables(h->rt, H0, W0, net_h, net_w, s))) return rc;
+    if ((rc = ensure_workspace(h, 0, batch, g, s))) return rc;
+    if ((rc = ensure_workspace(h, 1, batch, g, s))) return rc;
+
+    // fork: the side streams start after everything already queued on the caller's stream
+    CD_HIP(hipEventRecord(h->ev_fork, s));
+    CD_HIP(hipStreamWaitEvent(h->side_cls, h->ev_fork, 0));
+    if (two_pass) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_fork, 0));
+    const int64_t small_row = (int64_t)net_w * 3, small_frame = small_row * net_h;
+    for (int64_t i = 0; i < nb; ++i) {
+        const int64_t a = i * batch;
+        const int k = (int)std::min<int64_t>(batch, n - a);
+        hipStream_t st = (i & 1) ? h->side_cls : s;
+        const uint8_t* in = src + a * frame_stride;
+        const int slot = (int)(i % 3);
+        if (two_pass) {
+            uint8_t* dst = h->small + (size_t)slot * h->small_bytes;
+            if (i >= 3) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot
+            {
+                StageTimer t(h, CD_STAGE_PREPROCESS, h->side_pre);
+                if ((rc = launch_resize_u8(h, in, k, H0, W0, row_stride, frame_stride, dst, net_h, net_w, h->side_pre))) return rc;
+            }
+            CD_HIP(hipEventRecord(h->ev_ready[slot], h->side_pre));
+            CD_HIP(hipStreamWaitEvent(st, h->ev_ready[slot], 0));
+            rc = forward_u8_on(h, h->ws[i & 1], *rt, dst, k, net_h, net_w, small_row, small_frame, chan_order, g,
+                               logits + a * kOut, maxv ? maxv + a : nullptr, argmax ? argmax + a : nullptr, st, true);
+            if (rc) return rc;
+            CD_HIP(hipEventRecord(h->ev_free[slot], st));
+        } else {
+            rc = forward_u8_on(h, h->ws[i & 1], *rt, in, k, H0, W0, row_stride, frame_stride, chan_order, g,
+                               logits + a * kOut, maxv ? maxv + a : nullptr, argmax ? argmax + a : nullptr, st, true);
+            if (rc) return rc;
+        }
+    }
+    // join: everything this call queued anywhere is ordered before what the caller queues next
+    CD_HIP(hipEventRecord(h->ev_join, h->side_cls));
+    CD_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    return CD_OK;
 }
 
 int cd_rle(cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset, int64_t* end,
@@ -640,18 +776,18 @@ int cd_eval_accumulate(cd_handle* h, const float* logits, const int64_t* labels,
 #ifdef CD_DIAG
 // diagnostic builds only: copy bytes out of the block-1 activation workspace
 int cd_debug_peek_act1(cd_handle* h, size_t byte_off, size_t nbytes, void* host_dst) {
-    if (!h || byte_off + nbytes > h->act1_bytes) return CD_EINVAL;
+    if (!h || byte_off + nbytes > h->act1_bytes[0]) return CD_EINVAL;
     CD_HIP(hipDeviceSynchronize());
-    CD_HIP(hipMemcpy(host_dst, reinterpret_cast<char*>(h->act1) + byte_off, nbytes, hipMemcpyDeviceToHost));
+    CD_HIP(hipMemcpy(host_dst, reinterpret_cast<char*>(h->ws[0].act1) + byte_off, nbytes, hipMemcpyDeviceToHost));
     return CD_OK;
 }
 #endif
 
 #ifdef CD_DIAG
 int cd_debug_peek_act2(cd_handle* h, size_t byte_off, size_t nbytes, void* host_dst) {
-    if (!h || byte_off + nbytes > h->act2_bytes) return CD_EINVAL;
+    if (!h || byte_off + nbytes > h->act2_bytes[0]) return CD_EINVAL;
     CD_HIP(hipDeviceSynchronize());
-    CD_HIP(hipMemcpy(host_dst, reinterpret_cast<char*>(h->act2) + byte_off, nbytes, hipMemcpyDeviceToHost));
+    CD_HIP(hipMemcpy(host_dst, reinterpret_cast<char*>(h->ws[0].act2) + byte_off, nbytes, hipMemcpyDeviceToHost));
     return CD_OK;
 }
 #endif

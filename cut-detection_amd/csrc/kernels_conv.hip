@@ -865,56 +865,58 @@ static int c1_static_lds(int dtype) {
 }
 
 template <int MODE>
-static void launch_conv1(const cd_handle* h, unsigned grid, hipStream_t s, const float* x, const uint8_t* src,
+static void launch_conv1(const cd_handle* h, const Workspace& ws, unsigned grid, hipStream_t s, const float* x, const uint8_t* src,
                          const SampleArgs& sa, int64_t frame_stride, int chan_order, int n, const Geometry& g,
                          int chunks, int groups, int cpw, int stage_pitch = 0) {
     const size_t dyn = (size_t)2 * stage_pitch;
     if (h->dtype == CD_BF16)
         hipLaunchKernelGGL((conv1_bf16_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), dyn, s, x, src, sa, frame_stride,
                            chan_order, reinterpret_cast<const bf16x4*>(h->p.w1b), (const float*)h->p.post,
-                           reinterpret_cast<uint16_t*>(h->act1), n, g.h, g.h1, chunks, stage_pitch);
+                           reinterpret_cast<uint16_t*>(ws.act1), n, g.h, g.h1, chunks, stage_pitch);
     else if (h->dtype == CD_BF16_SPLIT) {
         if constexpr (MODE == 0)       // float frames are not exact in bfloat16: the fp32 block 1, split-bf16 output
             hipLaunchKernelGGL((conv1_kernel<MODE, kS2>), dim3(grid), dim3(256), dyn, s, x, src, sa, frame_stride, chan_order,
-                               (const float*)h->p.w1, reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, groups, cpw,
+                               (const float*)h->p.w1, reinterpret_cast<uint32_t*>(ws.act1), n, g.h, g.h1, chunks, groups, cpw,
                                stage_pitch);
         else
             hipLaunchKernelGGL((conv1_split_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), dyn, s, src, sa, frame_stride,
                                chan_order, reinterpret_cast<const u32x4*>(h->p.w1s), (const float*)h->p.post,
-                               reinterpret_cast<uint32_t*>(h->act1), n, g.h, g.h1, chunks, stage_pitch);
+                               reinterpret_cast<uint32_t*>(ws.act1), n, g.h, g.h1, chunks, stage_pitch);
     }
     else
         hipLaunchKernelGGL((conv1_kernel<MODE, kF32>), dim3(grid), dim3(256), dyn, s, x, src, sa, frame_stride, chan_order,
-                           (const float*)h->p.w1, h->act1, n, g.h, g.h1, chunks, groups, cpw, stage_pitch);
+                           (const float*)h->p.w1, ws.act1, n, g.h, g.h1, chunks, groups, cpw, stage_pitch);
 }
 
-int launch_conv1_f32(const cd_handle* h, const float* x, int n, const Geometry& g, hipStream_t s) {
+int launch_conv1_f32(const cd_handle* h, const Workspace& ws, const float* x, int n, const Geometry& g, hipStream_t s) {
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
     SampleArgs sa{};
     const int cpw = c1_chunks_per_wg(n, chunks), groups = (chunks + cpw - 1) / cpw;
-    launch_conv1<0>(h, xcd_grid(n, groups), s, x, nullptr, sa, 0, 0, n, g, chunks, groups, cpw);
+    launch_conv1<0>(h, ws, xcd_grid(n, groups), s, x, nullptr, sa, 0, 0, n, g, chunks, groups, cpw);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
 
-int launch_conv1_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
-                    int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s) {
+int launch_conv1_u8(const cd_handle* h, const Workspace& ws, const ResizeTables& rt, const uint8_t* src, int n, int H0,
+                    int W0, int64_t row_stride, int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s) {
     const int chunks = (g.h1 + kC1PoolRows - 1) / kC1PoolRows;
-    SampleArgs sa{h->rt.sx, h->rt.ax, h->rt.sy, h->rt.by, h->rt.mode, H0, W0, row_stride,
-                  h->rt.affine, h->rt.xm, h->rt.xa, h->rt.ym, h->rt.ya};
+    SampleArgs sa{rt.sx, rt.ax, rt.sy, rt.by, rt.mode, H0, W0, row_stride,
+                  rt.affine, rt.xm, rt.xa, rt.ym, rt.ya};
     const int cpw = c1_chunks_per_wg(n, chunks), groups = (chunks + cpw - 1) / cpw;
     if (W0 < 3) { set_error("cd_forward_u8: source frames must be at least 3 pixels wide"); return CD_EINVAL; }
     // General resize: source rows go through LDS when they are 16-byte aligned and two of them fit
-    // beside the kernel's static LDS in 64 KB (sources up to 4096 pixels wide in fp32, 2500 in split bf16); the last 16-byte piece of a row may reach up to 15 bytes
-    // past it, which stays inside the frame except on the last row of the last frame - there the
-    // per-thread gather variant runs instead (it never reads past a row).
+    // beside the kernel's static LDS in 64 KB (sources up to 4096 pixels wide in fp32, 2500 in split
+    // bf16).  The last 16-byte piece of a row may reach up to 15 bytes past its pixels: that is only
+    // done when it stays inside the row's own row_stride bytes (tail_ok below: whole rows of
+    // row_stride bytes are readable for every row, the last one included, which cd_forward_u8
+    // documents); otherwise the per-thread gather variant runs, which never reads past a row's pixels.
     const int row_bytes = W0 * 3, pitch = ((row_bytes + 15) & ~15) + 16;
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     const bool tail_ok = (row_bytes & 15) == 0 || row_stride >= (int64_t)((row_bytes + 15) & ~15);
-    if (h->rt.mode == 1) launch_conv1<1>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
+    if (rt.mode == 1) launch_conv1<1>(h, ws, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
     else if (aligned && tail_ok && 2 * pitch <= 65536 - c1_static_lds(h->dtype))
-        launch_conv1<2>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw, pitch);
-    else launch_conv1<3>(h, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
+        launch_conv1<2>(h, ws, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw, pitch);
+    else launch_conv1<3>(h, ws, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
@@ -1307,7 +1309,7 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
+int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s) {
     const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
     const int total = (int)xcd_grid(n, tiles_x * tiles_y);
     // persistent single-wave workgroups: one per SIMD in fp32 (the wave needs 308 registers and keeps
@@ -1317,14 +1319,14 @@ int launch_conv2(const cd_handle* h, int n, const Geometry& g, hipStream_t s) {
     const int grid = total < cap ? total : cap;
     if (h->dtype == CD_BF16)
         hipLaunchKernelGGL(conv2_kernel<kBF16>, dim3((unsigned)grid), dim3(64), 0, s,
-                           reinterpret_cast<const uint16_t*>(h->act1), reinterpret_cast<uint16_t*>(h->act2),
+                           reinterpret_cast<const uint16_t*>(ws.act1), reinterpret_cast<uint16_t*>(ws.act2),
                            (const void*)h->p.w2b, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     else if (h->dtype == CD_BF16_SPLIT)
         hipLaunchKernelGGL(conv2_kernel<kS2>, dim3((unsigned)grid), dim3(64), 0, s,
-                           reinterpret_cast<const uint32_t*>(h->act1), reinterpret_cast<uint32_t*>(h->act2),
+                           reinterpret_cast<const uint32_t*>(ws.act1), reinterpret_cast<uint32_t*>(ws.act2),
                            (const void*)h->p.w2s, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     else
-        hipLaunchKernelGGL(conv2_kernel<kF32>, dim3((unsigned)grid), dim3(64), 0, s, (const float*)h->act1, h->act2,
+        hipLaunchKernelGGL(conv2_kernel<kF32>, dim3((unsigned)grid), dim3(64), 0, s, (const float*)ws.act1, ws.act2,
                            (const void*)h->p.w2, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     CD_HIP(hipGetLastError());
     return CD_OK;
@@ -1555,7 +1557,7 @@ int init_conv3_head() {
     return CD_OK;
 }
 
-int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logits, float* maxv,
+int launch_conv3_head(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, float* logits, float* maxv,
                       int64_t* argmax, hipStream_t s) {
     const bool bf = h->dtype == CD_BF16;
     size_t lds = head_lds_bytes(g, bf ? 2 : 4);
@@ -1574,14 +1576,14 @@ int launch_conv3_head(const cd_handle* h, int n, const Geometry& g, float* logit
     }
     if (bf)
         hipLaunchKernelGGL(conv3_head_kernel<kBF16>, dim3((unsigned)n), dim3(256), lds, s,
-                           reinterpret_cast<const uint16_t*>(h->act2), (const void*)h->p.w3b, h->p.post + 6 * kC,
+                           reinterpret_cast<const uint16_t*>(ws.act2), (const void*)h->p.w3b, h->p.post + 6 * kC,
                            h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3, spare_off);
     else if (h->dtype == CD_BF16_SPLIT)
         hipLaunchKernelGGL(conv3_head_kernel<kS2>, dim3((unsigned)n), dim3(256), lds, s,
-                           reinterpret_cast<const uint32_t*>(h->act2), (const void*)h->p.w3s, h->p.post + 6 * kC,
+                           reinterpret_cast<const uint32_t*>(ws.act2), (const void*)h->p.w3s, h->p.post + 6 * kC,
                            h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b, logits, maxv, argmax, g.h2, g.h3, spare_off);
     else
-        hipLaunchKernelGGL(conv3_head_kernel<kF32>, dim3((unsigned)n), dim3(256), lds, s, (const float*)h->act2,
+        hipLaunchKernelGGL(conv3_head_kernel<kF32>, dim3((unsigned)n), dim3(256), lds, s, (const float*)ws.act2,
                            (const void*)h->p.w3, h->p.post + 6 * kC, h->p.fc0w, h->p.fc0p, h->p.fc1w, h->p.fc1b,
                            logits, maxv, argmax, g.h2, g.h3, spare_off);
     CD_HIP(hipGetLastError());

@@ -40,6 +40,7 @@ SIGNATURES = {
     "cd_nv12_to_bgr": (C.c_int, [_h, _p, _p, _i, _i, _l, _l, _l, _l, _p, _p, _i, _p, _i, _p]),
     "cd_forward": (C.c_int, [_h, _p, _i, _i, _i, _p, _p, _p, _p]),
     "cd_forward_u8": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),
+    "cd_forward_u8_range": (C.c_int, [_h, _p, _l, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),
     "cd_forward_u8_static": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),
     "cd_max_argmax": (C.c_int, [_h, _p, _l, _i, _p, _p, _p]),
     "cd_eval_accumulate": (C.c_int, [_h, _p, _p, _l, _i, _p, _p, _p, _p]),

@@ -38,8 +38,10 @@ class Engine:
     """One classifier instance on one GPU."""
 
     def __init__(self, blob, device="cuda:0", dtype="f32"):
-        """dtype "f32": the reference's arithmetic.  "bf16": blocks 2 and 3 on the bf16 matrix cores
-        with fp32 accumulation (logits move by about 1e-2; outputs stay fp32 tensors)."""
+        """dtype "f32": the reference's arithmetic.  "bf16_split": every convolution on the bf16 matrix
+        cores with each fp32 value carried as hi + lo bfloat16 and fp32 accumulation (logits within 1e-3
+        of f32; measured a few 1e-5).  "bf16": plain bfloat16 operands (logits move by a few 1e-2).
+        Outputs are fp32 tensors in all three."""
         if dtype not in _lib.DTYPES:
             raise ValueError(f"dtype must be one of {sorted(_lib.DTYPES)}, got {dtype!r}")
         self.dtype = dtype
@@ -182,6 +184,21 @@ class Engine:
         check(lib.cd_forward_u8(self._h, _ptr(frames), n, H0, W0, rs, fs, chan_order, nh, nw, _ptr(logits),
                                 _ptr(mx), _ptr(am), self._stream()))
         return (logits, mx, am) if want_max else logits
+
+    def forward_u8_range(self, frames, batch, out, chan_order=_lib.CD_BGR, resize=NET_W, net_h=None):
+        """The whole hot loop in one call: u8 [N,H0,W0,3] frames resident on the GPU, classified in
+        batches of `batch`; `out` = (logits [N,3], max [N], argmax [N]) to write into.  Bit-identical to
+        forward_u8 batch by batch; consecutive batches overlap on two streams inside the library and a
+        geometry that needs a real resize is resized one batch ahead on a third (cd_forward_u8_range)."""
+        n, H0, W0, rs, fs = self._frame_layout(frames)
+        nh, nw = output_size(H0, W0, resize)
+        if net_h is not None:
+            nh = int(net_h)
+        logits, mx, am = self._outputs(n, True, out)
+        if n:
+            check(lib.cd_forward_u8_range(self._h, _ptr(frames), n, int(batch), H0, W0, rs, fs, chan_order, nh, nw,
+                                          _ptr(logits), _ptr(mx), _ptr(am), self._stream()))
+        return logits, mx, am
 
     def forward_u8_static(self, frames, out, chan_order=_lib.CD_BGR, resize=NET_W, net_h=None):
         """forward_u8 through the library's entry point that allocates nothing: `out` = (logits, max,

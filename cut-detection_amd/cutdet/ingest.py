@@ -49,17 +49,23 @@ class BatchUploader:
         return k
 
     def batches(self, fill):
-        slot, k = 0, self._issue(0, fill)
-        while k:
-            compute = torch.cuda.current_stream(self.device)
-            compute.wait_event(self.uploaded[slot])
-            yield self.dev[slot][:k]
-            # whatever the consumer queued on its stream for this batch is now in front of this event
-            self.consumed[slot].record(torch.cuda.current_stream(self.device))
-            # read + upload the next batch while the GPU works on the one just handed over
-            nxt = (slot + 1) % self.depth
-            k = self._issue(nxt, fill)
-            slot = nxt
+        try:
+            slot, k = 0, self._issue(0, fill)
+            while k:
+                compute = torch.cuda.current_stream(self.device)
+                compute.wait_event(self.uploaded[slot])
+                yield self.dev[slot][:k]
+                # whatever the consumer queued on its stream for this batch is now in front of this event
+                self.consumed[slot].record(torch.cuda.current_stream(self.device))
+                # read + upload the next batch while the GPU works on the one just handed over
+                nxt = (slot + 1) % self.depth
+                k = self._issue(nxt, fill)
+                slot = nxt
+        finally:
+            # A consumer that stops early (a frame limit, an exception) may leave an upload in flight.
+            # The device buffers belong to the allocating stream's pool: once this object is dropped
+            # they can be handed to other tensors, so no copy may still be writing them.
+            self.copy_stream.synchronize()
 
 
 class ParallelCopier:

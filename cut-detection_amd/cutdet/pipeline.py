@@ -78,9 +78,12 @@ class SegmentCsvStream:
     caller, to a shared one).  Rows are `clip,<columns...>`; each clip's rows are written and
     flushed in one piece, so a reader following the file never sees half a clip."""
 
-    def __init__(self, path_or_file, columns=DEFAULT_COLUMNS, clip_column=True):
+    def __init__(self, path_or_file, columns=DEFAULT_COLUMNS, clip_column=True, lock=False):
+        """`lock`: take an exclusive advisory lock on the file (flock) around each clip's write, so
+        that several processes - one per GPU, each with the file open for appending - can share it."""
         self.columns = check_columns(columns)
         self.clip_column = bool(clip_column)
+        self.lock = bool(lock)
         self._own = isinstance(path_or_file, (str, bytes)) or hasattr(path_or_file, "__fspath__")
         self._f = open(path_or_file, "ab") if self._own else path_or_file
         self.clips = 0
@@ -93,8 +96,18 @@ class SegmentCsvStream:
             if any(ch in cid for ch in ',"\r\n'):
                 cid = '"' + cid.replace('"', '""') + '"'
             rows = [(cid,) + r for r in rows]
-        self._f.write(b"".join((",".join(r) + "\r\n").encode() for r in rows))
-        self._f.flush()
+        data = b"".join((",".join(r) + "\r\n").encode() for r in rows)
+        if self.lock:
+            import fcntl
+            fcntl.flock(self._f.fileno(), fcntl.LOCK_EX)
+            try:
+                self._f.write(data)
+                self._f.flush()
+            finally:
+                fcntl.flock(self._f.fileno(), fcntl.LOCK_UN)
+        else:
+            self._f.write(data)
+            self._f.flush()
         self.clips += 1
         self.rows += len(rows)
 
@@ -117,38 +130,54 @@ def shard_range(total, rank, world):
     return min(total, rank * per), min(total, (rank + 1) * per)
 
 
-def gather_streams(cls, maxv, group=None, total=None):
+def gather_streams(cls, maxv, group=None, total=None, force_collective=False):
     """(cls, maxv) of the whole clip on every rank, from each rank's contiguous frame range, in ONE
-    all-gather.  Ranks own the ranges of shard_range(total, rank, world), so every count is known
-    without asking: `total` defaults to world x this rank's count (equal shards).  Each rank
-    contributes one fixed-size payload, [cap] int64 classes followed by [cap] float32 maxima with
-    cap = ceil(total / world).  Works on any backend (RCCL for GPU tensors, gloo for CPU tensors);
-    without an initialised process group it is the identity."""
+    all-gather.  Ranks own the ranges of shard_range(total, rank, world), so every count follows from
+    `total` (required with more than one rank; all ranks must pass the same value - it sizes the
+    collective).  Each rank contributes one fixed-size payload: a 16-byte header (the number of frames
+    it actually holds, and `total`), [cap] int64 classes, [cap] float32 maxima, cap = ceil(total /
+    world).  A rank whose count is not what the split gives it still sends a payload of the right size,
+    so the collective completes, and then EVERY rank raises ValueError from the gathered headers (no
+    rank is left waiting inside the collective).  Works on any backend (RCCL for GPU tensors, gloo
+    for CPU tensors); without an initialised process group it is the identity.  `force_collective`
+    runs the all-gather even in a one-rank group (to exercise the backend)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return cls, maxv
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collective:
         return cls, maxv
     rank = dist.get_rank(group)
-    n_local = cls.shape[0]
-    total = world * n_local if total is None else int(total)
+    n_local = int(cls.shape[0])
+    if total is None:
+        if world > 1:
+            raise ValueError("gather_streams: `total` (frames of the whole clip) is required with more than one rank")
+        total = n_local
+    total = int(total)
     counts = [hi - lo for lo, hi in (shard_range(total, r, world) for r in range(world))]
-    if counts[rank] != n_local or maxv.shape[0] != n_local:
-        raise ValueError(f"rank {rank} holds {n_local} frames; the contiguous split of {total} frames over "
-                         f"{world} ranks gives it {counts[rank]}")
+    if maxv.shape[0] != n_local:
+        raise ValueError(f"rank {rank}: {n_local} classes but {maxv.shape[0]} maxima")
     out_dev = cls.device
     # gloo moves host memory only: stage through the CPU when the group is not RCCL
     dev = out_dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    cap = (max(counts) + 1) // 2 * 2          # even, so every rank's 12*cap-byte slot stays 8-byte aligned
-    pay = torch.zeros((cap * 12,), dtype=torch.uint8, device=dev)
-    pay[: n_local * 8] = cls.to(dev).contiguous().view(torch.uint8)
-    pay[cap * 8: cap * 8 + n_local * 4] = maxv.to(dev).contiguous().view(torch.uint8)
-    allpay = torch.empty((world * cap * 12,), dtype=torch.uint8, device=dev)
+    cap = (max(counts) + 1) // 2 * 2          # even, so every rank's slot stays 8-byte aligned
+    slot = 16 + cap * 12
+    k = min(n_local, cap)
+    pay = torch.zeros((slot,), dtype=torch.uint8, device=dev)
+    pay[:16] = torch.tensor([n_local, total], dtype=torch.int64).view(torch.uint8).to(dev)
+    pay[16: 16 + k * 8] = cls[:k].to(dev).contiguous().view(torch.uint8)
+    pay[16 + cap * 8: 16 + cap * 8 + k * 4] = maxv[:k].to(dev).contiguous().view(torch.uint8)
+    allpay = torch.empty((world * slot,), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(allpay, pay, group=group)
-    allpay = allpay.view(world, cap * 12)
-    out_cls = torch.cat([allpay[r, : counts[r] * 8].view(torch.int64) for r in range(world)])
-    out_max = torch.cat([allpay[r, cap * 8: cap * 8 + counts[r] * 4].view(torch.float32) for r in range(world)])
+    allpay = allpay.view(world, slot)
+    heads = allpay[:, :16].contiguous().view(torch.int64).cpu().tolist()
+    bad = [(r, h[0], counts[r]) for r, h in enumerate(heads) if h[0] != counts[r] or h[1] != total]
+    if bad:
+        r, got, want = bad[0]
+        raise ValueError(f"rank {r} holds {got} frames; the contiguous split of {total} frames over "
+                         f"{world} ranks gives it {want} (seen by rank {rank})")
+    out_cls = torch.cat([allpay[r, 16: 16 + counts[r] * 8].view(torch.int64) for r in range(world)])
+    out_max = torch.cat([allpay[r, 16 + cap * 8: 16 + cap * 8 + counts[r] * 4].view(torch.float32) for r in range(world)])
     return out_cls.to(out_dev), out_max.to(out_dev)
 
 
@@ -164,12 +193,8 @@ def finish_table(initial, real_threshold=100, blank_threshold=10, keep_lone_orph
 class ClipClassifier:
     """Classifies a clip batch by batch into clip-long device buffers, then segments it."""
 
-    def __init__(self, engine, n_frames, twin=None):
-        """`twin`: a second Engine on the same GPU; classify_range then alternates batches between
-        the two on two streams (see _classify_two_streams)."""
+    def __init__(self, engine, n_frames):
         self.engine = engine
-        self.twin = twin
-        self._twin_stream = None
         self.n_frames = int(n_frames)
         dev = engine.device
         self.logits = torch.empty((self.n_frames, 3), dtype=torch.float32, device=dev)
@@ -185,62 +210,20 @@ class ClipClassifier:
 
     def classify_range(self, frames_u8, offset=0, batch=256, chan_order=_lib.CD_BGR, overlap=True):
         """Classifies frames_u8 (u8 [N,H0,W0,3] on the GPU) in batches; results land at rows
-        offset .. offset+N.  When the resize is a pure point sample (1280x720 -> 256x144) every batch
-        is one fused call.  Otherwise, with `overlap`, the resize of batch i+1 (memory-bound:
-        cd_resize_u8 on a second stream) runs beside the classification of batch i (matrix-bound:
-        cd_forward_u8 on the resized frames), handed over by events; the logits are bit-identical to
-        the fused call's."""
-        from .engine import output_size, sampled_source_rows
-        n, H0, W0 = frames_u8.shape[0], frames_u8.shape[1], frames_u8.shape[2]
-        nh, nw = output_size(H0, W0)
-        if self.twin is not None:
-            return self._classify_two_streams(frames_u8, offset, batch, chan_order)
-        if not overlap or sampled_source_rows(H0, W0) is not None or (H0, W0) == (nh, nw):
-            for a in range(0, n, batch):
-                self.classify(frames_u8[a:a + batch], offset + a, chan_order)
-            return
-        eng, dev = self.engine, self.engine.device
-        key = (batch, nh, nw)
-        if getattr(self, "_small_key", None) != key:
-            self._small = [torch.empty((batch, nh, nw, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-            self._side = torch.cuda.Stream(device=dev)
-            self._ready = [torch.cuda.Event() for _ in range(2)]
-            self._free = [torch.cuda.Event() for _ in range(2)]
-            self._small_key = key
-        main = torch.cuda.current_stream(dev)
-        self._side.wait_stream(main)                 # the frames, and earlier readers of the small buffers
-        for i, a in enumerate(range(0, n, batch)):
-            b, s = min(n, a + batch), i % 2
-            with torch.cuda.stream(self._side):
-                if i >= 2:
-                    self._side.wait_event(self._free[s])
-                eng.resize_u8(frames_u8[a:b], out=self._small[s][:b - a])
-                self._ready[s].record(self._side)
-            main.wait_event(self._ready[s])
-            self.classify(self._small[s][:b - a], offset + a, chan_order)
-            self._free[s].record(main)
-
-    def _classify_two_streams(self, frames_u8, offset, batch, chan_order):
-        """Batches alternate between this engine on the current stream and a twin engine (its own
-        handle and activation workspace) on a second stream: the start-up and tail of one batch's
-        kernels fill with the other batch's work.  Results are complete once the current stream has
-        waited for the second one, which this does before returning."""
-        dev = self.engine.device
-        main = torch.cuda.current_stream(dev)
-        if self._twin_stream is None:
-            self._twin_stream = torch.cuda.Stream(device=dev)
-        side = self._twin_stream
-        side.wait_stream(main)
+        offset .. offset+N.  With `overlap` (default) the whole range is ONE library call
+        (cd_forward_u8_range): consecutive batches overlap on two streams inside the library, and a
+        geometry that needs a real resize is resized ahead on a third stream.  Without it every batch
+        is one fused cd_forward_u8 call on the current stream.  The results are bit-identical."""
         n = frames_u8.shape[0]
-        for i, a in enumerate(range(0, n, batch)):
-            sl = slice(offset + a, offset + min(n, a + batch))
-            out = (self.logits[sl], self.maxv[sl], self.cls[sl])
-            if i % 2 == 0:
-                self.engine.forward_u8(frames_u8[a:a + batch], chan_order=chan_order, out=out)
-            else:
-                with torch.cuda.stream(side):
-                    self.twin.forward_u8(frames_u8[a:a + batch], chan_order=chan_order, out=out)
-        main.wait_stream(side)
+        if n == 0:
+            return
+        if overlap:
+            sl = slice(offset, offset + n)
+            self.engine.forward_u8_range(frames_u8, batch, (self.logits[sl], self.maxv[sl], self.cls[sl]),
+                                         chan_order=chan_order)
+            return
+        for a in range(0, n, batch):
+            self.classify(frames_u8[a:a + batch], offset + a, chan_order)
 
     def gathered_streams(self, n_local, group=None, total=None):
         return gather_streams(self.cls[:n_local], self.maxv[:n_local], group, total)

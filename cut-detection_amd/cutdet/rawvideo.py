@@ -19,6 +19,7 @@ HEADER_BYTES = 64
 
 # the cv2.CAP_PROP_* ids the reference queries (frameID/data.py:20-24)
 CAP_PROP_FRAME_WIDTH, CAP_PROP_FRAME_HEIGHT, CAP_PROP_FPS, CAP_PROP_FRAME_COUNT = 3, 4, 5, 7
+CAP_PROP_POS_FRAMES = 1          # index of the frame the next read() returns (cv2's id for it)
 
 
 NV12 = 2
@@ -70,7 +71,17 @@ class RawVideoCapture:
 
     def get(self, prop):
         return float({CAP_PROP_FRAME_WIDTH: self.width, CAP_PROP_FRAME_HEIGHT: self.height,
-                      CAP_PROP_FPS: self.fps, CAP_PROP_FRAME_COUNT: self.length}.get(prop, 0))
+                      CAP_PROP_FPS: self.fps, CAP_PROP_FRAME_COUNT: self.length,
+                      CAP_PROP_POS_FRAMES: self._pos}.get(prop, 0))
+
+    def set(self, prop, value):
+        """cv2.VideoCapture.set for CAP_PROP_POS_FRAMES: the next read starts at frame `value` (a rank
+        that owns a frame range of the clip opens the file and seeks to its first frame).  Returns
+        False, like cv2, for a property it cannot set."""
+        if prop != CAP_PROP_POS_FRAMES:
+            return False
+        self._pos = min(max(int(value), 0), self.length)
+        return True
 
     def read(self):
         if self._pos >= self.length:

@@ -74,6 +74,7 @@ class VideoDataset(IterableDataset):
         self.batch_net_height = self.new_height if self.sampled_rows is not None else None
         self._copier = None
         self._ended = False
+        self._remaining = None       # frames left of the range set by seek(); None = no limit
         # NV12 containers (what hardware decoders deliver) are uploaded as planes - half the bytes of
         # BGR - and converted on the GPU; sampled-row upload takes the luma rows the resize reads and
         # the chroma row under each of them.
@@ -82,8 +83,28 @@ class VideoDataset(IterableDataset):
             self.chan_order = 0          # the converter writes BGR
 
     # --- decoded frames ------------------------------------------------------------------
+    def seek(self, frame_index, max_frames=None):
+        """The next frame read is `frame_index` and at most `max_frames` frames follow (None = to the
+        end): how a rank that owns the frame range [lo, hi) of a clip opens it, seek(lo, hi - lo).
+        OpenCV captures seek through CAP_PROP_POS_FRAMES, as the raw container does."""
+        if not self.cap.set(rawvideo.CAP_PROP_POS_FRAMES, int(frame_index)):
+            raise RuntimeError(f"the capture cannot seek to frame {frame_index}")
+        self._remaining = None if max_frames is None else max(0, int(max_frames))
+        self._ended = False
+        self._ready = None
+
     def _fill(self, out, rows):
         """Next decoded frames (only `rows` of each, if given) into out[:k]; returns k."""
+        if self._remaining is not None:
+            out = out[: min(out.shape[0], self._remaining)]
+            if out.shape[0] == 0:
+                return 0
+        k = self._fill_unbounded(out, rows)
+        if self._remaining is not None:
+            self._remaining -= k
+        return k
+
+    def _fill_unbounded(self, out, rows):
         if hasattr(self.cap, "read_batch_into"):
             if self._copier is None:
                 self._copier = ingest.ParallelCopier()

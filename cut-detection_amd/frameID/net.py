@@ -26,7 +26,7 @@ class ProdNet:
     def __init__(self, blob, params, dtype="f32"):
         self._blob = blob
         self.params = dict(params)
-        self.dtype = dtype            # "f32" (the reference's arithmetic) or "bf16" (see cutdet.Engine)
+        self.dtype = dtype            # "f32" (the reference's arithmetic), "bf16_split" or "bf16" (see cutdet.Engine)
         self._device = torch.device("cpu")
         self._engine = None
 
@@ -150,7 +150,8 @@ def load_and_glue_nets(param_file, conv_file, linear_file, dtype="f32"):
 # Load a specific network that's included in the module.
 def load_default_net(dtype="f32"):
     """The bundled production classifier (the same weights as the reference's prod_net).  `dtype` is
-    an addition to the reference's signature: "bf16" selects the bf16 matrix-core arithmetic."""
+    an addition to the reference's signature: "bf16_split" and "bf16" select the bf16 matrix-core
+    arithmetics (see cutdet.Engine; only "f32" and "bf16_split" keep the logits within 1e-3)."""
     with open(api.DEFAULT_MANIFEST, "r") as f:
         model_params = json.load(f)["model_params"]
     return ProdNet(api.default_blob(), model_params, dtype), model_params

@@ -66,9 +66,11 @@ enum {
  * Logits then differ from the fp32 result by a few 1e-2; class ids are unchanged on inputs with
  * clear margins.
  * CD_BF16_SPLIT: blocks 2 and 3 multiply fp32 values split into two bfloat16 terms each
- * (v = hi + lo to 2^-17) on the bf16 matrix cores, all four partial products, fp32 accumulation;
- * block 1, epilogues and head are fp32.  Logits stay within 1e-3 of the fp32 result (measured: a
- * few 1e-5 on the test clips). */
+ * (v = hi + lo to 2^-17) on the bf16 matrix cores, all four partial products, fp32 accumulation.
+ * Block 1 on u8 frames also runs on the bf16 matrix cores: a byte is exact in bfloat16, and the
+ * weights carry the 1/255 as hi + lo terms (block 1 on float frames, cd_forward, is fp32).
+ * Epilogues and head are fp32.  Logits stay within 1e-3 of the fp32 result (measured: a few 1e-5
+ * on the test clips). */
 enum { CD_F32 = 0, CD_BF16 = 1, CD_BF16_SPLIT = 2 };
 enum { CD_BGR = 0, CD_RGB = 1 };         /* channel order of u8 frames in memory */
 
@@ -133,11 +135,32 @@ int cd_forward(cd_handle* h, const float* x, int n, int net_h, int net_w,
                float* logits, float* maxv, int64_t* argmax, void* stream);
 
 /* cd_preprocess + cd_forward fused: the resized frame never reaches HBM.
- * Replaces the data.py:218-228 -> segment_video.py:44-45 chain for one batch. */
+ * Replaces the data.py:218-228 -> segment_video.py:44-45 chain for one batch.
+ * Every row of every frame must be readable for its full row_stride bytes (the last row of the last
+ * frame included): when row_stride is a multiple of 16 the general resize fetches rows in 16-byte
+ * pieces and may read up to 15 bytes past a row's W0*3 pixel bytes, never past row_stride. */
 int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
                   int64_t row_stride, int64_t frame_stride, int chan_order,
                   int net_h, int net_w,
                   float* logits, float* maxv, int64_t* argmax, void* stream);
+
+/* The reference's whole hot loop in one call: n decoded frames resident in device memory, classified
+ * in batches of `batch` frames.  Replaces segment_video.py:42-58 (`for batch in dl: yy.append(
+ * net(batch))`) together with the data.py:218-228 preprocessing of every frame.  src, strides,
+ * chan_order, net_h, net_w as in cd_forward_u8; logits [n][3], maxv [n], argmax [n] (the last two may
+ * be NULL) are written at the frames' own rows.  Results are bit-identical to calling cd_forward_u8
+ * batch by batch.  What the single-batch call cannot do: consecutive batches alternate between two
+ * activation workspaces, the caller's stream and a stream the handle owns, so the start-up, tail and
+ * per-frame serial phases of one batch's kernels fill with the other batch's work; and for source
+ * geometries that need a real resize (not a point sample) the resize of the batches ahead runs as a
+ * separate memory-bound pass on a third stream beside the matrix-bound classification.  The call
+ * forks from and joins back into `stream`: everything it queued is ordered before whatever the
+ * caller queues on `stream` afterwards, and it does not synchronise in the steady state (first use
+ * creates the two streams and the second workspace).  n <= batch is exactly cd_forward_u8. */
+int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, int H0, int W0,
+                        int64_t row_stride, int64_t frame_stride, int chan_order,
+                        int net_h, int net_w,
+                        float* logits, float* maxv, int64_t* argmax, void* stream);
 
 /* cd_forward_u8 for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
@@ -147,8 +170,12 @@ int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
  * 34 frames at a network input height of 144 rows (more at smaller heights); a larger batch returns
  * CD_ECAP.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (other
  * streams, other handles, other threads) race.  The first call on a device, and the first after the
- * input height changed, clears the array and synchronises `stream` once; a new source geometry
- * uploads the resize tables synchronously, as in cd_forward_u8. */
+ * input height or the activation cell size changed (CD_BF16 handles store 2-byte cells, the others
+ * 4-byte ones), clears the array and synchronises `stream` once; a new source geometry uploads the
+ * resize tables with a blocking copy, as in cd_forward_u8.  Neither is legal while `stream` is being
+ * captured into a HIP graph: warm the entry point up with one call outside the capture for each
+ * (device, dtype class, net_h, source geometry) that will be captured; calls after that queue only
+ * the three kernels.  GPUs with an index of 64 or more have no static array (CD_EINVAL). */
 int cd_forward_u8_static(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
                          int64_t row_stride, int64_t frame_stride, int chan_order,
                          int net_h, int net_w,

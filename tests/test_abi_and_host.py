@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, n), f"libcutdet.so does not export {n}"
         assert n in _lib.SIGNATURES, f"no ctypes signature for {n}"
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib.cd_version() == 2
+    assert _lib.lib.cd_version() == 3
 
 
 def test_create_rejects_garbage_without_touching_the_gpu():

@@ -68,10 +68,18 @@ def _worker(rank, world, port, n, out_dir):
     out = pipeline.finish_table(initial, 100, 10)
     with open(os.path.join(out_dir, f"csv{rank}.bin"), "wb") as f:
         f.write(out["csv"])
-    # a rank that claims a count the split does not give it is refused locally, before any collective
+    # ONE rank holds a count the split does not give it: the collective still completes (fixed-size
+    # payloads) and EVERY rank raises from the gathered headers - nobody is left inside the all-gather
+    cut = 1 if rank == world - 1 else 0
     try:
-        pipeline.gather_streams(torch.from_numpy(cls[lo:hi - 1]), torch.from_numpy(mx[lo:hi - 1]), total=n)
+        pipeline.gather_streams(torch.from_numpy(cls[lo:hi - cut]), torch.from_numpy(mx[lo:hi - cut]), total=n)
         raise AssertionError("wrong shard size accepted")
+    except ValueError as e:
+        assert f"rank {world - 1} holds" in str(e)
+    # without `total` the counts cannot be known: refused before any collective
+    try:
+        pipeline.gather_streams(torch.from_numpy(cls[lo:hi]), torch.from_numpy(mx[lo:hi]))
+        raise AssertionError("missing total accepted")
     except ValueError:
         pass
     dist.barrier()
@@ -129,6 +137,8 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["gathered_frames"] == 6000 and out["gather_ok"]
+    # the rendezvous of the no-process-group leg (file barrier + result exchange) saw both ranks
+    assert out["file_barrier_ranks"] == 2 and out["file_barrier_frames"] == 6000
 
 
 def test_bench_strong_split_and_failed_rank():
@@ -140,3 +150,47 @@ def test_bench_strong_split_and_failed_rank():
     r = _bench(["--gpus", "2", "--clip-frames", "2000"], CUTDET_BENCH_FAIL_RANK="1")
     assert r.returncode == 7
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_file_barrier_lines_up_processes(tmp_path):
+    """cutdet.launch.FileBarrier: ranks without a process group meet through files."""
+    for p in (ROOT, os.path.join(ROOT, "cut-detection_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import threading
+    from cutdet.launch import FileBarrier
+    world, got = 4, {}
+
+    def rank_body(r):
+        fb = FileBarrier(r, world, str(tmp_path), timeout=30)
+        fb.wait()
+        got[r] = fb.exchange("value", str(r * r))
+        fb.wait()
+
+    threads = [threading.Thread(target=rank_body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert all(got[r] == ["0", "1", "4", "9"] for r in range(world))
+    os.makedirs(tmp_path / "nobody")
+    with pytest.raises(TimeoutError):            # the other rank never arrives
+        FileBarrier(0, 2, str(tmp_path / "nobody"), timeout=0.2).wait()
+
+
+def test_raw_capture_seeks_like_cv2(tmp_path):
+    """RawVideoCapture.set(CAP_PROP_POS_FRAMES): a rank opens the clip at its frame range."""
+    for p in (ROOT, os.path.join(ROOT, "cut-detection_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from cutdet import rawvideo
+    frames = np.arange(7 * 4 * 6 * 3, dtype=np.uint8).reshape(7, 4, 6, 3)
+    path = str(tmp_path / "c.cdraw")
+    rawvideo.write_raw_video(path, frames)
+    cap = rawvideo.RawVideoCapture(path)
+    assert cap.set(rawvideo.CAP_PROP_POS_FRAMES, 5) and cap.get(rawvideo.CAP_PROP_POS_FRAMES) == 5
+    ok, f = cap.read()
+    assert ok and (f == frames[5]).all()
+    assert (cap.read_batch(10) == frames[6:]).all() and cap.read()[0] is False
+    assert cap.set(rawvideo.CAP_PROP_POS_FRAMES, 2) and (cap.read_batch(2) == frames[2:4]).all()
+    assert not cap.set(rawvideo.CAP_PROP_FPS, 60)

@@ -313,24 +313,52 @@ def test_overlapped_resize_pipeline_matches_the_fused_call(h, w, dtype):
     assert fused.cls.cpu().tolist() == cl
 
 
-def test_two_stream_batches_match_single_stream(engine):
-    """Batches alternating between two handles on two streams give the single-stream bits."""
+@pytest.mark.parametrize("dtype", ["f32", "bf16_split"])
+def test_range_entry_matches_single_batch_calls(dtype):
+    """cd_forward_u8_range (batches alternating between two workspaces on two streams inside the
+    library) gives the bits of cd_forward_u8 batch by batch, repeatedly, with a short last batch, and
+    its results are ordered on the caller's stream when it returns."""
     from cutdet import api, synth as csynth
-    from cutdet.engine import Engine
     from cutdet.pipeline import ClipClassifier
+    eng = api.default_engine("cuda:0", dtype)
     n = 700
     cl = csynth.classes_from_runs(csynth.run_table(n, SEED))
-    frames = engine.synth_frames(torch.tensor(cl, dtype=torch.uint8, device=engine.device), 720, 1280, SEED)
-    one = ClipClassifier(engine, n)
-    one.classify_range(frames, 0, 128)
-    twin = Engine(api.default_blob(), engine.device)
-    two = ClipClassifier(engine, n, twin=twin)
-    for _ in range(2):
+    frames = eng.synth_frames(torch.tensor(cl, dtype=torch.uint8, device=eng.device), 720, 1280, SEED)
+    one = ClipClassifier(eng, n)
+    one.classify_range(frames, 0, 128, overlap=False)
+    two = ClipClassifier(eng, n)
+    for _ in range(3):
         two.logits.fill_(float("nan"))
         two.classify_range(frames, 0, 128)          # 6 batches, the last one short
         assert torch.equal(two.logits, one.logits) and torch.equal(two.cls, one.cls)   # same stream: ordered after the join
+        assert torch.equal(two.maxv, one.maxv)
     assert two.segment()["csv"] == one.segment()["csv"]
-    twin.close()
+    # a range of one batch, and a range at an offset into the clip buffers
+    two.logits.fill_(float("nan"))
+    two.classify_range(frames[:100], 0, 128)
+    two.classify_range(frames[100:], 100, 256)
+    assert torch.equal(two.logits, one.logits)
+    # on a non-default stream
+    st = torch.cuda.Stream(device=eng.device)
+    st.wait_stream(torch.cuda.current_stream(eng.device))
+    with torch.cuda.stream(st):
+        two.logits.fill_(float("nan"))
+        two.classify_range(frames, 0, 64)
+        same = torch.equal(two.logits, one.logits)
+    st.synchronize()
+    assert same
+
+
+def test_range_entry_rejects_bad_arguments(engine):
+    from cutdet._lib import CutdetError
+    dev = engine.device
+    frames = torch.zeros((4, 180, 320, 3), dtype=torch.uint8, device=dev)
+    outs = (torch.zeros((4, 3), device=dev), torch.zeros((4,), device=dev), torch.zeros((4,), dtype=torch.int64, device=dev))
+    with pytest.raises(CutdetError):
+        engine.forward_u8_range(frames, 0, outs)                   # batch of 0
+    with pytest.raises(ValueError):
+        engine.forward_u8_range(frames, 2, (outs[0][:3], outs[1], outs[2]))
+    engine.forward_u8_range(frames[:0], 2, (outs[0][:0], outs[1][:0], outs[2][:0]))      # empty range: no-op
 
 
 # ----------------------------------------------------------------------------- argument checks of the newer entry points

@@ -67,3 +67,25 @@ def test_static_forward_matches_forward_u8_on_consecutive_calls():
     # the Python wrapper raises for the same case
     with pytest.raises(_lib.CutdetError):
         eng.forward_u8_static(big, _outs(dev, 36))
+
+
+def test_static_forward_alternating_cell_sizes_at_one_height():
+    """Handles of different arithmetics share the GPU's static array: an fp32 (or split-bf16) handle
+    stores 4-byte activation cells and a bf16 handle 2-byte ones over the same [rows][cols][48]
+    grid, so their zero borders lie at different addresses.  Alternating them at ONE network height
+    must still reproduce each handle's cd_forward_u8 bit for bit."""
+    from cutdet import _lib, api
+    lib = _lib.lib
+    engines = [api.default_engine("cuda:0", d) for d in ("f32", "bf16", "bf16_split", "bf16", "f32")]
+    dev = engines[0].device
+    cl = [0, 1, 2, 1, 0, 2, 1, 1, 0, 0, 2, 1, 0, 2]
+    frames = engines[0].synth_frames(torch.tensor(cl, dtype=torch.uint8, device=dev), 720, 1280, SEED, first_index=11)
+    torch.cuda.synchronize()
+    for eng in engines:
+        want, got = _outs(dev, len(cl)), _outs(dev, len(cl))
+        assert _call(lib, "cd_forward_u8", eng, frames, 144, want) == _lib.CD_OK
+        assert _call(lib, "cd_forward_u8_static", eng, frames, 144, got) == _lib.CD_OK, lib.cd_last_error()
+        torch.cuda.synchronize()
+        for w, g in zip(want, got):
+            assert torch.equal(w, g), eng.dtype
+        assert got[2].cpu().tolist() == cl
