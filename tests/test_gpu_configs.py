@@ -38,6 +38,22 @@ def engine():
     return api.default_engine("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _release_hbm():
+    """The full-size cases hold most of the GPU's memory; give it back to the driver afterwards (the
+    caching allocator would keep it) so that the rank processes other tests start find room."""
+    yield
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _errors(stderr):
+    """The lines of a failed child's stderr that name an error, then its tail."""
+    hits = [ln for ln in stderr.splitlines() if "Error" in ln or "error" in ln]
+    return "\n".join(hits[:20]) + "\n...\n" + stderr[-2000:]
+
+
 def _cli():
     spec = importlib.util.spec_from_file_location("cd_segment_video", os.path.join(PKG, "segment_video.py"))
     mod = importlib.util.module_from_spec(spec)
@@ -250,7 +266,7 @@ def test_bench_driver_command_with_8_ranks_reports_all_three_shapes():
         e.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
                         "--leg-steps", "1", "--leg-warmup", "1"], env=e, capture_output=True, text=True, timeout=560)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, _errors(r.stderr)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and lines[0] == r.stdout.strip()
     out = json.loads(lines[0])
@@ -271,7 +287,7 @@ def test_bench_one_gpu_line_has_config4_and_the_separate_roofline_pass():
         e.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=280)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, _errors(r.stderr)
     out = json.loads(r.stdout.strip())
     assert out["n_gpus"] == 1 and out["dtype"] == "f32" and out["config"]["frames_per_step"] == 10_000
     assert out["roofline"]["bound"] == "mfma" and out["roofline"]["launches_timed"] == 80
