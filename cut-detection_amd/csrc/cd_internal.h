@@ -113,10 +113,11 @@ struct cd_handle {
     // cd_forward_u8_range: side streams (classification of every other batch; stand-alone resize) and
     // the events that fork from / join into the caller's stream and hand resized batches over
     hipStream_t side_cls, side_pre;
-    hipEvent_t ev_fork, ev_join, ev_ready[3], ev_free[3];
+    hipEvent_t ev_fork, ev_join, ev_ready[3], ev_free[3], ev_a1ready[2], ev_a1free[2];
     uint8_t* small;         // resized frames of up to three batches in flight: [3][small_frames][net_h][256][3]
     size_t small_bytes;     // bytes of one of the three slots
     int64_t* rle_blocks;    // workspace of cd_rle: per-block boundary counts / offsets
+    double* rle_sums;       // ... and per-block fp64 sums of the maxima (same number of entries)
     int rle_blocks_cap;
     // optional per-stage timing: HIP event pairs recorded around each stage's launches
     unsigned timing;   // bit i set: launches of stage i are bracketed

@@ -394,6 +394,16 @@ bool resize_is_point_sample(int H0, int W0, int nh, int nw) {
     return point;
 }
 
+// How cd_forward_u8_range spreads a range over its streams: 0 = whole batches alternate between two
+// streams, 1 = block 1 of every batch on one stream and blocks 2 + 3 on the other.  CUTDET_RANGE_MODE
+// overrides the default (for measurements); both give the same bits.
+int range_mode(const cd_handle* h) {
+    static const int forced = [] { const char* e = std::getenv("CUTDET_RANGE_MODE"); return e ? std::atoi(e) : -1; }();
+    if (forced == 0 || forced == 1) return forced;
+    (void)h;
+    return 0;
+}
+
 // Streams and events of cd_forward_u8_range, created on first use (with the handle's device current).
 int ensure_range_state(cd_handle* h) {
     if (h->side_cls) return CD_OK;
@@ -404,8 +414,9 @@ int ensure_range_state(cd_handle* h) {
         set_error("cd_forward_u8_range: cannot create a stream");
         return CD_EHIP;
     }
-    hipEvent_t* ev[8] = {&h->ev_fork, &h->ev_join, &h->ev_ready[0], &h->ev_ready[1], &h->ev_ready[2],
-                         &h->ev_free[0], &h->ev_free[1], &h->ev_free[2]};
+    hipEvent_t* ev[12] = {&h->ev_fork, &h->ev_join, &h->ev_ready[0], &h->ev_ready[1], &h->ev_ready[2],
+                          &h->ev_free[0], &h->ev_free[1], &h->ev_free[2], &h->ev_a1ready[0], &h->ev_a1ready[1],
+                          &h->ev_a1free[0], &h->ev_a1free[1]};
     for (hipEvent_t* e : ev)
         if (!*e) CD_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     h->side_pre = b;
@@ -492,6 +503,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     }
     h->rle_blocks_cap = 1 << 16;   // x 4096 frames per block
     CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->rle_blocks), (size_t)h->rle_blocks_cap * sizeof(int64_t)));
+    CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->rle_sums), (size_t)h->rle_blocks_cap * sizeof(double)));
 #undef CD_TRY
     if (init_conv3_head() != CD_OK) return fail(CD_EHIP);
     if (init_static_scratch(device) != CD_OK) return fail(CD_EHIP);
@@ -512,9 +524,11 @@ void cd_destroy(cd_handle* h) {
     if (h->side_cls) (void)hipStreamDestroy(h->side_cls);
     if (h->side_pre) (void)hipStreamDestroy(h->side_pre);
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_ready[0], h->ev_ready[1], h->ev_ready[2], h->ev_free[0],
-                         h->ev_free[1], h->ev_free[2]})
+                         h->ev_free[1], h->ev_free[2], h->ev_a1ready[0], h->ev_a1ready[1], h->ev_a1free[0],
+                         h->ev_a1free[1]})
         if (e) (void)hipEventDestroy(e);
     if (h->rle_blocks) (void)hipFree(h->rle_blocks);
+    if (h->rle_sums) (void)hipFree(h->rle_sums);
     for (int st = 0; st < CD_STAGE_COUNT; ++st) {
         for (hipEvent_t e : h->ev_start[st]) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->ev_stop[st]) (void)hipEventDestroy(e);
@@ -706,12 +720,19 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     CD_HIP(hipStreamWaitEvent(h->side_cls, h->ev_fork, 0));
     if (two_pass) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_fork, 0));
     const int64_t small_row = (int64_t)net_w * 3, small_frame = small_row * net_h;
+    const int mode = range_mode(h);
     for (int64_t i = 0; i < nb; ++i) {
         const int64_t a = i * batch;
         const int k = (int)std::min<int64_t>(batch, n - a);
-        hipStream_t st = (i & 1) ? h->side_cls : s;
+        const int par = (int)(i & 1), slot = (int)(i % 3);
+        // mode 0: the whole batch on one of two alternating streams.  mode 1: block 1 of every batch on the
+        // side stream, blocks 2 and 3 on the caller's stream, handed over through the two workspaces.
+        hipStream_t st1 = mode == 1 ? h->side_cls : (par ? h->side_cls : s);
+        hipStream_t st2 = mode == 1 ? s : st1;
+        const Workspace& ws = h->ws[par];
         const uint8_t* in = src + a * frame_stride;
-        const int slot = (int)(i % 3);
+        int fH = H0, fW = W0;
+        int64_t frs = row_stride, ffs = frame_stride;
         if (two_pass) {
             uint8_t* dst = h->small + (size_t)slot * h->small_bytes;
             if (i >= 3) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot
@@ -720,16 +741,24 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
                 if ((rc = launch_resize_u8(h, in, k, H0, W0, row_stride, frame_stride, dst, net_h, net_w, h->side_pre))) return rc;
             }
             CD_HIP(hipEventRecord(h->ev_ready[slot], h->side_pre));
-            CD_HIP(hipStreamWaitEvent(st, h->ev_ready[slot], 0));
-            rc = forward_u8_on(h, h->ws[i & 1], *rt, dst, k, net_h, net_w, small_row, small_frame, chan_order, g,
-                               logits + a * kOut, maxv ? maxv + a : nullptr, argmax ? argmax + a : nullptr, st, true);
-            if (rc) return rc;
-            CD_HIP(hipEventRecord(h->ev_free[slot], st));
-        } else {
-            rc = forward_u8_on(h, h->ws[i & 1], *rt, in, k, H0, W0, row_stride, frame_stride, chan_order, g,
-                               logits + a * kOut, maxv ? maxv + a : nullptr, argmax ? argmax + a : nullptr, st, true);
-            if (rc) return rc;
+            CD_HIP(hipStreamWaitEvent(st1, h->ev_ready[slot], 0));
+            in = dst; fH = net_h; fW = net_w; frs = small_row; ffs = small_frame;
         }
+        if (mode == 1 && i >= 2) CD_HIP(hipStreamWaitEvent(st1, h->ev_a1free[par], 0));   // block 2 of batch i-2 has read act1
+        {
+            StageTimer t(h, CD_STAGE_CONV1, st1);
+            if ((rc = launch_conv1_u8(h, ws, *rt, in, k, fH, fW, frs, ffs, chan_order, g, st1))) return rc;
+        }
+        if (two_pass) CD_HIP(hipEventRecord(h->ev_free[slot], st1));
+        if (mode == 1) {
+            CD_HIP(hipEventRecord(h->ev_a1ready[par], st1));
+            CD_HIP(hipStreamWaitEvent(st2, h->ev_a1ready[par], 0));
+        }
+        { StageTimer t(h, CD_STAGE_CONV2, st2); if ((rc = launch_conv2(h, ws, k, g, st2))) return rc; }
+        if (mode == 1) CD_HIP(hipEventRecord(h->ev_a1free[par], st2));
+        StageTimer t(h, CD_STAGE_CONV3_HEAD, st2);
+        if ((rc = launch_conv3_head(h, ws, k, g, logits + a * kOut, maxv ? maxv + a : nullptr,
+                                    argmax ? argmax + a : nullptr, st2))) return rc;
     }
     // join: everything this call queued anywhere is ordered before what the caller queues next
     CD_HIP(hipEventRecord(h->ev_join, h->side_cls));

@@ -21,9 +21,12 @@
  *
  * What is pinned against the reference and what is not
  *   - fp32 forward, max/argmax, run-length tables, glue/merge and CSV are checked against outputs of
- *     the reference itself (logits to 1e-3, everything else exact; per-segment means are fp64 sums
- *     rounded once, within 2 ulp of the reference's fp32 torch.mean - a pick between two orphans
- *     whose means agree to that precision may differ).
+ *     the reference itself (logits to 1e-3, everything else exact, the per-segment means included:
+ *     for segments shorter than 32768 frames cd_rle adds the maxima in the order of torch's CPU
+ *     float32 sum kernel, so the mean - which decides the order in which orphans are glued - is the
+ *     reference's torch.mean bit for bit.  From 32768 elements on torch splits a reduction over its
+ *     threads and the reference's own value depends on the machine; there the mean is the fp64 sum
+ *     rounded once).
  *   - the resize for geometries other than an odd integer scale (a pure point sample such as
  *     1280x720 -> 256x144) restates OpenCV's published 8-bit INTER_LINEAR arithmetic without an
  *     OpenCV build to compare with: parity unpinned.
@@ -202,8 +205,9 @@ int cd_eval_accumulate(cd_handle* h, const float* logits, const int64_t* labels,
 /* Run-length encodes a per-frame class stream into segments.
  * Replaces frameID/segmentation.py:39-60 (Segmentation.__init__ after the max).
  * cls (i64 [n]) and maxv (f32 [n]) are device arrays.  Outputs are device arrays of capacity
- * `cap` rows: end, type, runlen, start (i64), mean (f32: per-segment mean of maxv), sum (f64,
- * may be NULL: per-segment sum of maxv).  frame_offset is added to every start/end.
+ * `cap` rows: end, type, runlen, start (i64), mean (f32: per-segment mean of maxv, formed as
+ * torch.mean forms it on a CPU float32 slice - see the top of this file), sum (f64, may be NULL:
+ * per-segment sum of maxv).  frame_offset is added to every start/end.
  * n_seg: device i64[1], receives the number of segments found (even when it exceeds cap, in
  * which case only the first cap rows are written and the caller must treat it as CD_ECAP). */
 int cd_rle(cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset,

@@ -20,6 +20,70 @@ CLASS_NAMES = {0: "a22", 1: "ez", 2: "b"}
 KEYS = ("end_frames", "frame_types", "run_lengths", "start_frames", "score_means")
 
 
+def sum_f32_torch_order(x):
+    """fp32 sum of a contiguous 1-D float32 array in the order torch's CPU kernel adds it
+    (ATen SumKernel: 8-float vectors, four interleaved vector accumulators, the cascade levels of
+    multi_row_sum, then the scalar tail and the eight lanes one after the other; fewer than 8
+    elements: four interleaved scalar accumulators).  `highest_scores[a:b].mean()` in the reference
+    (segmentation.py:54-59) is this sum divided by the length, in fp32, for slices below the 32768
+    elements from which torch splits a reduction over threads.  Checked bit for bit against
+    torch.mean in tests/test_oracle_golden.py."""
+    x = np.asarray(x, dtype=np.float32)
+    n, V = int(x.shape[0]), 8
+    f = np.float32
+
+    def row_sum(load, size, width):
+        size_ilp = size // 4
+        ceil_log2 = 1 if size_ilp <= 2 else (size_ilp - 1).bit_length()
+        power = max(4, ceil_log2 // 4)
+        step, mask = 1 << power, (1 << power) - 1
+        zero = lambda: np.zeros(width, dtype=np.float32)  # noqa: E731
+        acc = [[zero() for _ in range(4)] for _ in range(4)]
+        i = 0
+        while i + step <= size_ilp:
+            for _ in range(step):
+                for k in range(4):
+                    acc[0][k] = acc[0][k] + load(4 * i + k)
+                i += 1
+            for j in range(1, 4):
+                for k in range(4):
+                    acc[j][k] = acc[j][k] + acc[j - 1][k]
+                    acc[j - 1][k] = zero()
+                if i & (mask << (j * power)):
+                    break
+        while i < size_ilp:
+            for k in range(4):
+                acc[0][k] = acc[0][k] + load(4 * i + k)
+            i += 1
+        for j in range(1, 4):
+            for k in range(4):
+                acc[0][k] = acc[0][k] + acc[j][k]
+        ps = acc[0]
+        for i in range(size_ilp * 4, size):
+            ps[0] = ps[0] + load(i)
+        for k in range(1, 4):
+            ps[0] = ps[0] + ps[k]
+        return ps[0]
+
+    with np.errstate(all="ignore"):
+        if n < V:
+            return f(row_sum(lambda i: x[i:i + 1], n, 1)[0])
+        vec_size = n // V
+        lanes = row_sum(lambda i: x[i * V:(i + 1) * V], vec_size, V)
+        total = f(0)
+        for k in range(vec_size * V, n):
+            total = f(total + x[k])
+        for k in range(V):
+            total = f(total + lanes[k])
+        return total
+
+
+def mean_f32_torch_order(x):
+    x = np.asarray(x, dtype=np.float32)
+    with np.errstate(all="ignore"):
+        return np.float32(sum_f32_torch_order(x) / np.float32(x.shape[0]))
+
+
 def segments_from_scores(scores):
     """scores float32 [N,3] -> segment table."""
     s = torch.as_tensor(np.asarray(scores, dtype=np.float32))
@@ -27,6 +91,7 @@ def segments_from_scores(scores):
         raise IndexError("no frames")
     best, cls = torch.max(s, dim=1)
     cls_l = cls.tolist()
+    best_np = best.numpy()
     n = len(cls_l)
     ends = [i for i in range(n - 1) if cls_l[i + 1] != cls_l[i]] + [n - 1]
     starts = [0] + [e + 1 for e in ends[:-1]]
@@ -35,8 +100,9 @@ def segments_from_scores(scores):
         "frame_types": [cls_l[e] for e in ends],
         "run_lengths": [e - b + 1 for b, e in zip(starts, ends)],
         "start_frames": starts,
-        # fp32 torch.mean over the slice, as the reference does
-        "score_means": [np.float32(best[b:e + 1].mean().item()) for b, e in zip(starts, ends)],
+        # fp32 torch.mean over the slice, as the reference does (its summation order restated, so
+        # that the result does not depend on the torch build of the machine the tests run on)
+        "score_means": [mean_f32_torch_order(best_np[b:e + 1]) for b, e in zip(starts, ends)],
     }
 
 

@@ -157,7 +157,9 @@ def _ref_means(tab):
 
 RLE_CASES = ["ten_runs", "equal_neighbours_tie", "prev_larger", "first_orphan", "last_orphan", "tie_rows",
              "many_orphans", "chain_merge", "single_frame", "single_short_segment", "all_orphans",
-             "custom_thresholds", "long_clip"]
+             "custom_thresholds", "long_clip",
+             "close_pair_p1ulp", "close_pair_m1ulp", "close_pair_p2ulp", "close_pair_m2ulp", "close_pair_p8ulp",
+             "close_pair_m8ulp", "close_triple_1ulp", "close_triple_2ulp", "close_triple_mixed"]
 
 
 @pytest.mark.parametrize("name", RLE_CASES)
@@ -170,7 +172,8 @@ def test_rle_matches_reference_tables(engine, golden_dir, name):
     for k in ("end_frames", "frame_types", "run_lengths", "start_frames"):
         assert te[k].dtype == torch.int64
         assert te[k].cpu().tolist() == c["init"][k], k
-    np.testing.assert_allclose(te["score_means"].cpu().numpy(), _ref_means(c["init"]), rtol=1e-6)
+    # the per-segment means are the reference's fp32 torch.mean values bit for bit
+    assert te["score_means"].cpu().numpy().tobytes() == _ref_means(c["init"]).tobytes()
 
 
 def test_rle_offset_capacity_and_large_stream(engine):
@@ -191,7 +194,7 @@ def test_rle_offset_capacity_and_large_stream(engine):
     assert te["start_frames"].cpu().tolist() == [s + 1000 for s in want["start_frames"]]
     assert te["run_lengths"].cpu().tolist() == want["run_lengths"]
     assert te["frame_types"].cpu().tolist() == want["frame_types"]
-    np.testing.assert_allclose(te["score_means"].cpu().numpy(), np.array(want["score_means"]), rtol=1e-6)
+    assert te["score_means"].cpu().numpy().tobytes() == np.array(want["score_means"], dtype=np.float32).tobytes()
     # size-independent property: run lengths tile the stream exactly
     assert int(te["run_lengths"].sum().item()) == n
     from cutdet._lib import CutdetError
@@ -399,7 +402,58 @@ def test_segmentation_class_error_cases(engine, golden_dir):
         s.combine_adjacent_segments()
         assert s.te["start_frames"].tolist() == c["merged"]["start_frames"]
         assert s.te["frame_types"].tolist() == c["merged"]["frame_types"]
-        np.testing.assert_allclose(s.te["score_means"].numpy(), _ref_means(c["merged"]), rtol=2e-6)
+        assert s.te["score_means"].numpy().tobytes() == _ref_means(c["merged"]).tobytes()
+
+
+@pytest.mark.parametrize("name", [n for n in RLE_CASES if n.startswith("close_")])
+def test_close_orphan_means_glue_in_the_reference_order(engine, golden_dir, name, tmp_path):
+    """Adjacent orphans whose score means differ by 1, 2 or 8 float32 steps: which one is glued first
+    (the smallest mean, segmentation.py:104-107) moves the segment boundary in the CSV.  The whole
+    chain - GPU max/argmax, run-length pass with the reference's fp32 mean, host glue and merge -
+    must give the reference's tables bit for bit and its CSV byte for byte."""
+    import base64
+    from frameID.segmentation import Segmentation
+    cases, arrays = _seg_golden(golden_dir)
+    c = cases[name]
+    s = Segmentation(torch.from_numpy(arrays[name]).to(engine.device))
+    for stage, step in (("init", None), ("glued", lambda: s.glue_orphans(*c["thresholds"])),
+                        ("merged", s.combine_adjacent_segments)):
+        if step:
+            step()
+        for k in ("end_frames", "frame_types", "run_lengths", "start_frames"):
+            assert s.te[k].tolist() == c[stage][k], (stage, k)
+        assert s.te["score_means"].numpy().tobytes() == _ref_means(c[stage]).tobytes(), stage
+    p = tmp_path / "o.csv"
+    s.write_csv(str(p))
+    assert p.read_bytes() == base64.b64decode(c["csv_b64"])
+
+
+def test_segment_means_follow_torch_mean_at_every_length(engine):
+    """Every segment length from 1 to 300, lengths around the vector and cascade boundaries of
+    torch's sum kernel, and the longest length that still takes that path: the GPU's per-segment mean
+    equals the oracle's restatement of torch.mean (itself checked against torch) bit for bit.  From
+    32768 frames on the mean is the fp64 sum rounded once."""
+    from oracle import segmentation
+    rs = np.random.RandomState(11)
+    lengths = list(range(1, 301)) + [511, 512, 513, 1023, 1024, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 32767,
+                                      32768, 50_000, 300_001]
+    rs.shuffle(lengths)
+    cls = np.concatenate([np.full(n, i % 3, np.int64) for i, n in enumerate(lengths)])
+    mx = rs.uniform(0.5, 9, size=cls.shape[0]).astype(np.float32)
+    te = engine.rle(torch.from_numpy(cls).to(engine.device), torch.from_numpy(mx).to(engine.device), frame_offset=17)
+    assert te["run_lengths"].cpu().tolist() == lengths
+    got = te["score_means"].cpu().numpy()
+    sums = te["score_sums"].cpu().numpy()
+    a = 0
+    for i, n in enumerate(lengths):
+        seg = mx[a:a + n]
+        a += n
+        exact = seg.astype(np.float64).sum()
+        assert abs(sums[i] - exact) <= 1e-12 * exact
+        if n < 32768:
+            assert got[i] == segmentation.mean_f32_torch_order(seg), n
+        else:
+            assert got[i] == np.float32(sums[i] / n), n
 
 
 def test_full_size_properties_10k_frames_720p(engine):

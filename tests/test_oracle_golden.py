@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import torch
 import pytest
 
 from oracle import net as onet
@@ -105,7 +106,11 @@ def _check_table(te, ref, exact_means):
 
 SEG_CASES = ["ten_runs", "equal_neighbours_tie", "prev_larger", "first_orphan", "last_orphan", "tie_rows",
              "many_orphans", "chain_merge", "single_frame", "single_short_segment", "all_orphans", "empty",
-             "custom_thresholds", "long_clip"]
+             "custom_thresholds", "long_clip",
+             # two / three adjacent orphans whose score means are 1, 2 and 8 float32 steps apart: the order
+             # in which they are glued, and with it the CSV, hangs on the exact fp32 mean of the reference
+             "close_pair_p1ulp", "close_pair_m1ulp", "close_pair_p2ulp", "close_pair_m2ulp", "close_pair_p8ulp",
+             "close_pair_m8ulp", "close_triple_1ulp", "close_triple_2ulp", "close_triple_mixed"]
 
 
 @pytest.mark.parametrize("name", SEG_CASES)
@@ -185,3 +190,34 @@ def test_synth_classes_and_determinism():
     assert synth.frame(SEED, 0, 2, 8, 16).max() <= 7
     e = synth.frame(SEED, 0, 1, 720, 1280)
     assert e[0:5].min() >= 230 and e[5:60, :, 1].min() >= 128 and e[5:60, :, 0].max() <= 33
+
+
+def test_mean_restatement_is_torch_mean_bit_for_bit():
+    """oracle.segmentation.mean_f32_torch_order against torch.mean on this machine: every length up
+    to 70, lengths around the vector / cascade boundaries, up to just below the 32768 elements from
+    which torch splits the reduction over threads."""
+    rs = np.random.RandomState(7)
+    for n in list(range(1, 71)) + [127, 128, 129, 511, 512, 513, 1023, 2049, 4095, 4096, 8191, 8192, 8193, 20011, 32767]:
+        for scale in (1.0, 1e-3):
+            x = (rs.uniform(1, 9, size=n) * scale).astype(np.float32)
+            assert segmentation.mean_f32_torch_order(x) == np.float32(torch.from_numpy(x).mean().item()), n
+
+
+def test_close_means_cases_separate_the_fp32_mean_from_a_rounded_fp64_mean(golden_dir):
+    """What the close-means fixtures are for: in some of them the order of two orphans' means under
+    the reference's fp32 summation is NOT the order of the exactly rounded means, so an
+    implementation that sums in fp64 and rounds once picks the other orphan first."""
+    cases, arrays = _load_seg(golden_dir)
+    flips = []
+    for name in SEG_CASES:
+        if not name.startswith("close_pair"):
+            continue
+        s = arrays[name]
+        best = s.max(axis=1)
+        a, b = best[300:330], best[330:360]
+        f32 = (segmentation.mean_f32_torch_order(a), segmentation.mean_f32_torch_order(b))
+        f64 = (np.float32(a.astype(np.float64).sum() / 30), np.float32(b.astype(np.float64).sum() / 30))
+        assert f32[0] != f32[1]
+        if (f32[0] < f32[1]) != (f64[0] < f64[1]) or f64[0] == f64[1]:
+            flips.append(name)
+    assert flips, "no fixture distinguishes the two summations"

@@ -9,6 +9,7 @@
 #                                           rocprofv3 kernel trace of `bench.py TRACE ARGS`, then one PMC pass per
 #                                           counter group of `bench.py PMC ARGS`, summarised by tools/summarize_prof.py
 #                                           into gpurun_out/prof_NAME/summary.md (copy what is to be kept to profiles/)
+#   tools/gpu.sh trace NAME [bench args]   kernel trace of bench.py + tools/trace_overlap.py (timeline, overlap)
 #   tools/gpu.sh py <script> [args]         a python tool under a time limit (tools/*.py)
 #
 # Every GPU step runs under its own time limit and the script stops at the first failure.
@@ -78,6 +79,16 @@ profile)
   find $OUT -name "*_kernel_trace.csv" -size +2M -delete
   find $OUT -name "*_counter_collection.csv" -size +2M -delete
   cat $OUT/summary.md
+  ;;
+trace)   # NAME [bench args]: kernel trace only, timeline + overlap analysis kept under gpurun_out/trace_NAME/
+  NAME=$1; shift
+  OUT=gpurun_out/trace_$NAME
+  rm -rf $OUT && mkdir -p $OUT
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 bench.py --no-cpu-baseline "$@" \
+    > $OUT/bench.json 2> $OUT/trace.err || { tail -5 $OUT/trace.err; exit 1; }
+  python3 tools/trace_overlap.py $OUT/t > $OUT/overlap.txt
+  find $OUT -name "*_kernel_trace.csv" -size +8M -delete
+  tail -12 $OUT/overlap.txt; cat $OUT/bench.json | cut -c1-300
   ;;
 py)
   timeout -k 10 600 python3 -u "$@"
