@@ -86,6 +86,18 @@ class ProdNet:
             val.update(x, y, chan_order=chan_order)
         return val.result()
 
+    def torchscript(self, example=None):
+        """What training_scripts/make_torchscript_model.py:25-34 does with the reference's net:
+        `torch.jit.trace` on a random [1,3,144,256] input; the returned module can be `.save()`d.  The
+        forward is one registered operator (cutdet.torchscript), traced == eager bit for bit.  Only the
+        bundled weights can be exported this way (the operator finds them by device, a saved file
+        cannot carry a library handle)."""
+        from cutdet import api, torchscript
+        if bytes(self._blob) != api.default_blob():
+            raise NotImplementedError("only the bundled prod_net can be traced; other weights travel as the "
+                                      "three model files (save_reference_files)")
+        return torchscript.trace(self.dtype, self.engine.device, example)[0]
+
     def state_dicts(self):
         """(conv_state_dict, linear_state_dict) of torch tensors with the reference's tensor names
         (frameID/net.py FrameConvNet / FrameLinearNet), BatchNorm counters included (as zero: the

@@ -386,3 +386,29 @@ def test_new_entry_points_reject_bad_arguments(engine):
                                nine[:3], nine[:3].clone(), torch.zeros((1,), dtype=torch.float64, device=dev))
     # an empty batch is a no-op for the wrappers, an error at the ABI
     assert engine.resize_u8(torch.zeros((0, 90, 160, 3), dtype=torch.uint8, device=dev)).shape == (0, 144, 256, 3)
+
+
+# ----------------------------------------------------------------------------- TorchScript consumer
+def test_forward_traces_as_one_operator_and_survives_save_and_load(engine, tmp_path):
+    """The reference's exporter (training_scripts/make_torchscript_model.py:25-34): trace on a random
+    [1,3,144,256] input, compare traced with eager, save.  Here the forward is one registered operator;
+    the traced module must give eager's bits, on other batch sizes too, also after a save / load
+    round trip in a fresh process that has only imported cutdet.torchscript."""
+    import subprocess
+    import sys
+    from cutdet import torchscript as ts
+    traced, eager = ts.trace("f32", engine.device)
+    assert "cutdet::prod_net_forward" in str(traced.graph)
+    x = torch.rand((5, 3, 144, 256), device=engine.device)
+    want = engine.forward(x)
+    assert torch.equal(eager(x), want) and torch.equal(traced(x), want)
+    path = str(tmp_path / "saved_model_trace.pt")
+    traced.save(path)
+    torch.save(x.cpu(), str(tmp_path / "x.pt"))
+    torch.save(want.cpu(), str(tmp_path / "y.pt"))
+    code = ("import sys, torch; sys.path.insert(0, sys.argv[1]); import cutdet.torchscript; "
+            "m = torch.jit.load(sys.argv[2]); x = torch.load(sys.argv[3]).cuda(); "
+            "y = m(x).cpu(); assert torch.equal(y, torch.load(sys.argv[4])); print('LOADED_OK')")
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "cut-detection_amd"), path,
+                        str(tmp_path / "x.pt"), str(tmp_path / "y.pt")], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "LOADED_OK" in r.stdout, (r.stdout + r.stderr)[-2000:]
