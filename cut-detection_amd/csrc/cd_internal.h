@@ -43,6 +43,13 @@ constexpr int c1_tap(int k) {
     if (pair == 12) return second ? -(2 * 100 + 10 + 0) - 1 : 2 * 100 + 20 + 0;  // (2,2,0) + pad at (2,1,0)
     return 2 * 100 + 20 + 1 + second;                                          // (2,2,1), (2,2,2)
 }
+// Operand-cell frames of the fused block 1 + 2 kernel (split bf16): 8-byte cells {R, G, B, 0} in bfloat16,
+// [kCellPad + net_h + kCellPad rows][kCellPitch cells] per frame, pixel (y, x) at row y + kCellPad, cell
+// x + kCellPad, everything else zero.  The margin of 4 makes the 44-cell rows a conv-2 tile needs start
+// on 16-byte boundaries (cell 36 * tile) and keeps them inside the pitch.
+constexpr int kCellPad = 4;
+constexpr int kCellPitch = kNetW + kCellPad;     // 260 cells = 2080 bytes per row
+inline size_t cell_frame_bytes(int net_h) { return (size_t)(net_h + 2 * kCellPad) * kCellPitch * 8; }
 constexpr int kMaxSrcW = 8192;  // widest source frame the resize tables are sized for
 constexpr int kMaxNetH = 215;   // tallest network input whose block-2 activation fits the head kernel's LDS
 constexpr int kLdsBytes = 160 * 1024;
@@ -116,6 +123,9 @@ struct cd_handle {
     hipEvent_t ev_fork, ev_join, ev_ready[3], ev_free[3], ev_a1ready[2], ev_a1free[2];
     uint8_t* small;         // resized frames of up to three batches in flight: [3][small_frames][net_h][256][3]
     size_t small_bytes;     // bytes of one of the three slots
+    uint8_t* cells;         // split bf16: operand-cell frames of up to three batches in flight (see kCellPad)
+    size_t cells_bytes;     // bytes of one of the three slots ((frames + 1) x cell_frame_bytes)
+    int cells_h;            // network input height the cell frames' zero margins are laid out for
     int64_t* rle_blocks;    // workspace of cd_rle: per-block boundary counts / offsets
     double* rle_sums;       // ... and per-block fp64 sums of the maxima (same number of entries)
     int rle_blocks_cap;
@@ -145,6 +155,12 @@ int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int
 int launch_resize_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
                      int64_t frame_stride, uint8_t* dst, int nh, int nw, hipStream_t s);
 // (the forward kernels read and write the activation buffers of `ws`; `rt` holds the resize tables)
+bool resize_cells_supported(const uint8_t* src, int W0, int64_t row_stride, int64_t frame_stride, int nw);
+int launch_resize_cells(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                        int64_t frame_stride, int chan_order, uint8_t* cells, int nh, int nw, hipStream_t s);
+// blocks 1 + 2 fused (split bf16 only): operand-cell frames in, block-2 activations of `ws` out
+int launch_conv12_split(const cd_handle* h, const Workspace& ws, const uint8_t* cells, int n, const Geometry& g,
+                        hipStream_t s);
 int launch_conv1_f32(const cd_handle* h, const Workspace& ws, const float* x, int n, const Geometry& g, hipStream_t s);
 int launch_conv1_u8(const cd_handle* h, const Workspace& ws, const ResizeTables& rt, const uint8_t* src, int n, int H0,
                     int W0, int64_t row_stride, int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s);

@@ -404,6 +404,12 @@ int range_mode(const cd_handle* h) {
     return 0;
 }
 
+// CUTDET_FUSED12=0 keeps split-bf16 ranges on the separate block-1 and block-2 kernels (for measurements)
+bool fused12_enabled() {
+    static const bool on = [] { const char* e = std::getenv("CUTDET_FUSED12"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // Streams and events of cd_forward_u8_range, created on first use (with the handle's device current).
 int ensure_range_state(cd_handle* h) {
     if (h->side_cls) return CD_OK;
@@ -521,6 +527,7 @@ void cd_destroy(cd_handle* h) {
         if (h->ws[k].act2) (void)hipFree(h->ws[k].act2);
     }
     if (h->small) (void)hipFree(h->small);
+    if (h->cells) (void)hipFree(h->cells);
     if (h->side_cls) (void)hipStreamDestroy(h->side_cls);
     if (h->side_pre) (void)hipStreamDestroy(h->side_pre);
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_ready[0], h->ev_ready[1], h->ev_ready[2], h->ev_free[0],
@@ -694,10 +701,32 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     // A geometry that needs a real resize goes through a stand-alone resize pass one batch ahead
     // (memory-bound) beside the classification of resized frames (matrix-bound); a point-sampling
     // geometry, and frames that already have the network's size, go straight into the fused block 1.
-    const bool two_pass = !(H0 == net_h && W0 == net_w) && !resize_is_point_sample(H0, W0, net_h, net_w);
+    // Split bf16: every geometry goes through the resize pass, which writes the first block's operand
+    // cells, and blocks 1 + 2 run as one kernel whose block-1 activations stay in LDS.
+    const bool fused12 = h->dtype == CD_BF16_SPLIT && fused12_enabled() &&
+                         resize_cells_supported(src, W0, row_stride, frame_stride, net_w);
+    const bool two_pass = fused12 || (!(H0 == net_h && W0 == net_w) && !resize_is_point_sample(H0, W0, net_h, net_w));
     if ((rc = ensure_range_state(h))) return rc;
     const ResizeTables* rt = &h->rt;
-    if (two_pass) {
+    if (fused12) {
+        if ((rc = ensure_tables(h->rt_pre, H0, W0, net_h, net_w, s))) return rc;
+        const size_t slot = (size_t)(batch + 1) * cell_frame_bytes(net_h);
+        if (slot > h->cells_bytes || h->cells_h != net_h) {
+            CD_HIP(hipStreamSynchronize(s));
+            CD_HIP(hipStreamSynchronize(h->side_cls));
+            CD_HIP(hipStreamSynchronize(h->side_pre));
+            if (slot > h->cells_bytes) {
+                if (h->cells) CD_HIP(hipFree(h->cells));
+                h->cells = nullptr; h->cells_bytes = 0;
+                CD_HIP(hipMalloc(reinterpret_cast<void**>(&h->cells), 3 * slot));
+                h->cells_bytes = slot;
+            }
+            // the margins of the cell frames are zero and never written; another height moves them
+            CD_HIP(hipMemsetAsync(h->cells, 0, 3 * h->cells_bytes, s));
+            CD_HIP(hipStreamSynchronize(s));
+            h->cells_h = net_h;
+        }
+    } else if (two_pass) {
         if ((rc = ensure_tables(h->rt_pre, H0, W0, net_h, net_w, s))) return rc;
         if ((rc = ensure_tables(h->rt_id, net_h, net_w, net_h, net_w, s))) return rc;
         rt = &h->rt_id;
@@ -720,7 +749,7 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     CD_HIP(hipStreamWaitEvent(h->side_cls, h->ev_fork, 0));
     if (two_pass) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_fork, 0));
     const int64_t small_row = (int64_t)net_w * 3, small_frame = small_row * net_h;
-    const int mode = range_mode(h);
+    const int mode = fused12 ? 0 : range_mode(h);
     for (int64_t i = 0; i < nb; ++i) {
         const int64_t a = i * batch;
         const int k = (int)std::min<int64_t>(batch, n - a);
@@ -733,6 +762,26 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
         const uint8_t* in = src + a * frame_stride;
         int fH = H0, fW = W0;
         int64_t frs = row_stride, ffs = frame_stride;
+        if (fused12) {
+            uint8_t* dst = h->cells + (size_t)slot * h->cells_bytes;
+            if (i >= 3) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot
+            {
+                StageTimer t(h, CD_STAGE_PREPROCESS, h->side_pre);
+                if ((rc = launch_resize_cells(h, in, k, H0, W0, row_stride, frame_stride, chan_order, dst, net_h, net_w,
+                                              h->side_pre))) return rc;
+            }
+            CD_HIP(hipEventRecord(h->ev_ready[slot], h->side_pre));
+            CD_HIP(hipStreamWaitEvent(st1, h->ev_ready[slot], 0));
+            {   // blocks 1 + 2 in one kernel, timed as block 2
+                StageTimer t(h, CD_STAGE_CONV2, st1);
+                if ((rc = launch_conv12_split(h, ws, dst, k, g, st1))) return rc;
+            }
+            CD_HIP(hipEventRecord(h->ev_free[slot], st1));
+            StageTimer t(h, CD_STAGE_CONV3_HEAD, st1);
+            if ((rc = launch_conv3_head(h, ws, k, g, logits + a * kOut, maxv ? maxv + a : nullptr,
+                                        argmax ? argmax + a : nullptr, st1))) return rc;
+            continue;
+        }
         if (two_pass) {
             uint8_t* dst = h->small + (size_t)slot * h->small_bytes;
             if (i >= 3) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot

@@ -1333,6 +1333,316 @@ int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry&
 }
 
 // ------------------------------------------------------------------------------------------
+// Blocks 1 + 2 fused (split bf16): the block-1 activations never reach HBM.
+//
+// Same persistent single-wave workgroups and the same wave tile as conv2_kernel (4x4 pool windows of
+// block 2 = a 14x14 patch of block-1 activations x 48 channels), but the patch is not copied from
+// HBM: the wave computes it.  Its input is the 44x44 neighbourhood of the resized frame, held in LDS
+// as the 8-byte operand cells {R, G, B, 0} (bfloat16 byte values) that the resize pass wrote to HBM
+// - a plain strided copy, so it arrives by LDS-DMA while the previous tile's last unit runs.  Per
+// 16-channel group g the wave then alternates
+//     produce(g): 14 patch rows x (27 MFMAs of K = 32: three kernel rows x nine conv pixels-groups,
+//                 the arithmetic of conv1_split_kernel; ReLU + 3x3 max + affine in registers; the
+//                 results written to LDS as the {hi x 4, lo x 4} cells block 2 reads; pixels outside
+//                 the frame are block 2's zero padding and are written as zeros)
+//     consume(g): the 9 steps x 54 MFMAs of conv2_unit on that patch.
+// The halo of a tile is recomputed ((14/12)^2 = 1.36 x the block-1 MFMAs), which is cheap next to the
+// 835 KB per frame of activations written and read back otherwise.  LDS per wave: 15.1 KB of input
+// cells + two 12.25 KB patch buffers = 40 576 bytes, four waves per CU.
+// Values are bit-identical to conv1_split_kernel followed by conv2_kernel<kS2>.
+// ------------------------------------------------------------------------------------------
+constexpr int kFIn = 44;                              // input cells per side of a tile's neighbourhood
+constexpr int kFInPieces = kFIn * (kFIn * 8 / 16);    // 968 16-byte pieces
+constexpr int kFInDma = (kFInPieces + 63) / 64;       // 16 wave-wide copies (the last one's surplus lands in patch buffer 0)
+constexpr int kFInBytes = kFIn * kFIn * 8;            // 15 488
+constexpr int kFPatchElems = kG2Pix * 16;             // one channel group of a patch, in 4-byte elements
+constexpr int kFLds = kFInBytes + 2 * kFPatchElems * 4;
+
+// produce(G): rows of the patch are wave tiles of 16 pool windows (14 used).  `cbase[j]` is the cell
+// (within an input row) that A-row lane&15 of column group j reads, kernel column lane>>4 included.
+template <int G>
+__device__ __forceinline__ void conv12_produce(const uint2* cin, uint32_t* pb, const u32x4 (&bw)[3][3],
+                                               const float (&p1)[3][3], const int (&cbase)[3], int lane,
+                                               int Y0, int X0, int H1) {
+    const int q = lane >> 4, ch = lane & 15;
+    const float bias = p1[G][0], sc = p1[G][1], sh = p1[G][2];
+    const f32x4 bias4 = f32x4{bias, bias, bias, bias};
+    uint16_t* out = reinterpret_cast<uint16_t*>(pb) + (ch >> 2) * 8 + (ch & 3);     // + pixel * 32; lo at + 4
+    auto cell = [&](int row, int j) {
+        const uint2 c = cin[cbase[j] + row * kFIn];
+        return u32x4{c.x, c.y, c.x, c.y};
+    };
+    auto finish = [&](const f32x4 (&acc)[3][3], int r) {
+        const float m[4] = {window_max<0>(acc), window_max<1>(acc), window_max<2>(acc), window_max<3>(acc)};
+        const bool row_in = (unsigned)(Y0 + r) < (unsigned)H1;
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi) {
+            const int x = 4 * q + wi;
+            const bool in = row_in && (unsigned)(X0 + x) < (unsigned)kW1;
+            const float v = in ? fmaf(m[wi], sc, sh) : 0.f;
+            const uint32_t hi = pack_bf16(v, 0.f) & 0xFFFFu;
+            const uint32_t lo = pack_bf16(v - __uint_as_float(hi << 16), 0.f);
+            if (x < kP2) {
+                out[(r * kP2 + x) * 32] = (uint16_t)hi;
+                out[(r * kP2 + x) * 32 + 4] = (uint16_t)lo;
+            }
+        }
+    };
+    u32x4 a[5][3];
+#pragma unroll
+    for (int rr = 0; rr < 5; ++rr)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[rr][j] = cell(rr, j);
+    f32x4 prev[3][3];
+#pragma unroll
+    for (int r = 0; r < kP2; ++r) {
+        // the three new input rows of the next patch row are requested before this row's MFMAs
+        u32x4 nx[3][3];
+        if (r + 1 < kP2) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) nx[rr][j] = cell(3 * (r + 1) + 2 + rr, j);
+        }
+        f32x4 acc[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t + ky][j]),
+                                                                        __builtin_bit_cast(bf16x8, bw[ky][G]),
+                                                                        ky == 0 ? bias4 : acc[t][j], 0, 0, 0);
+        // the previous row's pooling / affine / split / LDS writes are independent of these MFMAs
+        if (r > 0) finish(prev, r - 1);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) prev[t][j] = acc[t][j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            a[0][j] = a[3][j]; a[1][j] = a[4][j];
+            if (r + 1 < kP2) { a[2][j] = nx[0][j]; a[3][j] = nx[1][j]; a[4][j] = nx[2][j]; }
+        }
+        // (a row's loads, MFMAs and the previous row's epilogue are scheduled together, but not
+        // across rows: left free, the compiler requests every row's cells at once and spills)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    finish(prev, kP2 - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// byte offset of lane's piece of wave-wide copy `it` of a tile's input cells (22 pieces per 44-cell row;
+// pieces past the last row re-read it and land behind the cells in LDS)
+__device__ __forceinline__ int conv12_in_rel(int it, int lane) {
+    const int f = it * 64 + lane, row = min(f / 22, kFIn - 1), pc = f % 22;
+    return row * (kCellPitch * 8) + pc * 16;
+}
+
+// consume(G): conv2_unit on a patch that is complete when it starts.  Weight fragments are requested
+// two steps ahead across units and tiles as in conv2_kernel; the A operands of a unit's first step are
+// read at its start (the patch did not exist earlier).  In the last unit of a tile the copies of the
+// next tile's input cells are dealt out behind step 0's operand loads.
+template <int G>
+__device__ __forceinline__ void conv12_consume(const uint32_t* pb, const int (&base)[3], __amdgpu_buffer_rsrc_t wr,
+                                               int lane, u32x4 (&a)[2][3][3], SplitB (&b)[3][3], f32x4 (&acc)[3][3][3],
+                                               const char* next_cells, char* cin_lds) {
+    constexpr int kM = 54, kBD = 2, kNB = 3, kFirst = G * 9;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kBD - 1) * 6) : "memory");
+    constexpr int c0 = kFirst & 1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[c0][t][j] = *reinterpret_cast<const u32x4*>(pb + base[j] + t * kP2 * 16);
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+        const int c = (kFirst + kk) & 1;
+        const int bc = (kFirst + kk) % kNB, bn = (kFirst + kk + kBD) % kNB;
+        const int bstep = (kFirst + kk + kBD) % 27, bg = bstep / 9, bk = bstep % 9;
+        const int nk = kk + 1;
+        const int off = ((nk / 3) * kP2 + (nk % 3)) * 16;
+        const int n_ops = kk < 8 ? 12 : 3;
+        const int n_side = n_ops + (G == 2 && kk == 0 ? kFInDma : 0);
+        static_assert(12 + kFInDma <= kM, "more memory instructions than MFMAs in a step");
+#pragma unroll
+        for (int m = 0; m < kM; ++m) {
+            const int e = m / 27, t = (m / 9) % 3, j = (m / 3) % 3, nt = m % 3;
+            if (G == 0 && kk == 0 && e == 0)
+                acc[t][j][nt] = mfma_frag<kS2>(a[c][t][j], b[bc][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
+            else
+                acc[t][j][nt] = mfma_frag<kS2>(a[c][t][j], b[bc][nt], e, acc[t][j][nt]);
+            if (m < n_side) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < 3) {
+                    b[bn][m] = load_frag<kS2>(wr, lane, (bk * 3 + bg) * 3 + m);
+                } else if (m < n_ops) {
+                    const int lt = (m - 3) / 3, lj = (m - 3) % 3;
+                    a[c ^ 1][lt][lj] = *reinterpret_cast<const u32x4*>(pb + base[lj] + off + lt * kP2 * 16);
+                } else {
+                    const int it = m - n_ops;
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(next_cells + (uint32_t)conv12_in_rel(it, lane)),
+                        (__attribute__((address_space(3))) void*)(cin_lds + it * 1024), 16, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(64) void conv12_split_kernel(const uint8_t* __restrict__ cells, uint32_t* __restrict__ out,
+                                                          const u32x4* __restrict__ w1, const float* __restrict__ post1,
+                                                          const void* __restrict__ w2, const float* __restrict__ post2,
+                                                          int n, int H, int H1, int Hp, int tiles_x, int tiles_y,
+                                                          int total_tiles) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kFLds];
+    uint2* cin = reinterpret_cast<uint2*>(lds);
+    uint32_t* pb0 = reinterpret_cast<uint32_t*>(lds + kFInBytes);
+    uint32_t* pb1 = pb0 + kFPatchElems;
+    const int lane = threadIdx.x;
+    const int per_frame = tiles_x * tiles_y;
+    const int64_t in_frame = (int64_t)(H + 2 * kCellPad) * kCellPitch * 8, out_frame = (int64_t)(Hp + 2) * kP2W * kC;
+    auto valid = [&](int id) {
+        int frame, tt;
+        xcd_frame_tile(id, per_frame, frame, tt);
+        return id < total_tiles && frame < n;
+    };
+    struct Tile { const char* src; uint32_t* dst; int ty, tx; };
+    // invalid ids map to tile 0 of frame 0, so that the last look-ahead copy of a wave stays in bounds
+    auto locate = [&](int id) {
+        int frame = 0, tt = 0;
+        if (valid(id)) xcd_frame_tile(id, per_frame, frame, tt);
+        Tile t;
+        t.ty = tt / tiles_x; t.tx = tt % tiles_x;
+        t.src = reinterpret_cast<const char*>(cells) + frame * in_frame + ((int64_t)(36 * t.ty) * kCellPitch + 36 * t.tx) * 8;
+        t.dst = out + frame * out_frame;
+        return t;
+    };
+    int id = blockIdx.x;
+    if (!valid(id)) return;
+
+    const int i = lane & 15, kq = lane >> 4;
+    int base[3], cbase[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * 16 + 4 * kq;
+        const int c12 = 4 * j + (i & 3), d = (c12 * 11) >> 5, m = c12 - 3 * d;      // d = c12 / 3
+        const int W = min(4 * (i >> 2) + d, kP2 - 1);
+        // (lanes kq = 3 carry zero weights; they re-read the kq = 2 cell)
+        cbase[j] = 3 * W + m + min(kq, 2);
+    }
+    const __amdgpu_buffer_rsrc_t wr = weight_rsrc<kS2>(w2);
+    // block-1 weight fragments (ky, n-tile) and both blocks' bias / BatchNorm terms stay in registers
+    u32x4 bw[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) bw[ky][nt] = w1[(ky * 3 + nt) * 64 + lane];
+    float p1[3][3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p1[nt][k] = post1[k * kC + nt * 16 + (lane & 15)];
+
+    Tile cur = locate(id);
+    int next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
+    Tile nxt = locate(next_id);
+    u32x4 a[2][3][3];
+    SplitB b[3][3];
+    f32x4 acc[3][3][3];
+#pragma unroll
+    for (int it = 0; it < kFInDma; ++it)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cur.src + (uint32_t)conv12_in_rel(it, lane)),
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(lds) + it * 1024),
+                                         16, 0, 0);
+    // weight fragments of the first two steps (step s of a tile = kernel tap s % 9 of channel group s / 9)
+#pragma unroll
+    for (int s0 = 0; s0 < 2; ++s0)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) b[s0][nt] = load_frag<kS2>(wr, lane, ((s0 % 9) * 3 + s0 / 9) * 3 + nt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    for (;;) {
+        // the input cells of this tile (copied during the previous tile's last unit) have landed:
+        // VMEM completes in issue order and only weight loads were issued after the copies
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int Y0 = 12 * cur.ty - 1, X0 = 12 * cur.tx - 1;
+#pragma unroll
+        for (int s0 = 0; s0 < 2; ++s0)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) { asm volatile("" : "+v"(b[s0][nt].h)); asm volatile("" : "+v"(b[s0][nt].l)); }
+        conv12_produce<0>(cin, pb1, bw, p1, cbase, lane, Y0, X0, H1);
+        conv12_consume<0>(pb1, base, wr, lane, a, b, acc, nxt.src, reinterpret_cast<char*>(lds));
+        conv12_produce<1>(cin, pb0, bw, p1, cbase, lane, Y0, X0, H1);
+        conv12_consume<1>(pb0, base, wr, lane, a, b, acc, nxt.src, reinterpret_cast<char*>(lds));
+        conv12_produce<2>(cin, pb1, bw, p1, cbase, lane, Y0, X0, H1);
+        // block 2's bias / BatchNorm terms are only needed by the epilogue: requested here (older than
+        // every load the last unit issues, so its waits cover them), they do not occupy registers
+        // during the produce phases
+        float p2[3][3];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p2[nt][k] = post2[k * kC + nt * 16 + (lane & 15)];
+        // every read of the input cells is done (their values fed MFMAs that have issued): the next
+        // tile's cells may overwrite them, which consume<2> starts in its first step
+        conv12_consume<2>(pb1, base, wr, lane, a, b, acc, nxt.src, reinterpret_cast<char*>(lds));
+        // pooled + normalised results -> HBM, transposed through the patch buffer just consumed
+        {
+            float* scratch = reinterpret_cast<float*>(pb1);
+            const int q = lane >> 4, ch = lane & 15;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const int c = nt * 16 + ch;
+                const float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
+                                    window_max<3>(acc, nt)};
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi)
+                    scratch[(4 * q + wi) * kC + c] = fmaf(fmaxf(m[wi] + p2[nt][0], 0.f), p2[nt][1], p2[nt][2]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int f = it * 64 + lane;                 // 16-byte piece f of 16 windows x 192 bytes
+                const int win = f / 12, c4 = f % 12;
+                const int py = cur.ty * 4 + (win >> 2), px = cur.tx * 4 + (win & 3);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + win * kC + 4 * c4);
+                if (py < Hp && px < kW2)
+                    *reinterpret_cast<u32x4*>(cur.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = split_bf16(v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (next_id < 0) break;
+        id = next_id;
+        cur = nxt;
+        next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
+        nxt = locate(next_id);
+    }
+    // the look-ahead copy and weight loads of a tile that will never run are still in flight
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+int launch_conv12_split(const cd_handle* h, const Workspace& ws, const uint8_t* cells, int n, const Geometry& g,
+                        hipStream_t s) {
+    const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
+    const int total = (int)xcd_grid(n, tiles_x * tiles_y);
+    const int grid = total < 1024 ? total : 1024;
+    hipLaunchKernelGGL(conv12_split_kernel, dim3((unsigned)grid), dim3(64), 0, s, cells, reinterpret_cast<uint32_t*>(ws.act2),
+                       reinterpret_cast<const u32x4*>(h->p.w1s), (const float*)h->p.post, (const void*)h->p.w2s,
+                       h->p.post + 3 * kC, n, g.h, g.h1, g.h2, tiles_x, tiles_y, total);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Block 3 + head: one workgroup (4 waves) per frame.
 // The whole zero-padded block-2 activation ((Hin+2) x 30 x 48 fp32) sits in LDS; pool windows
 // are enumerated row-major, 16 per wave tile (45 windows = 3 tiles at 144 input rows).  The

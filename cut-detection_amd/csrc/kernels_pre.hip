@@ -115,9 +115,14 @@ int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int
 // row staging as preprocess_rows_kernel, the resized pixels written interleaved in the source's
 // channel order.  One workgroup per (frame, output row): at 1080p 2 x 5760 bytes in, 768 out.
 // ------------------------------------------------------------------------------------------
+// CELLS: the resized pixels are written as the first block's matrix-core operand cells instead of bytes
+// - 8 bytes per pixel, {R, G, B, 0} as bfloat16 (a byte value is exact in bfloat16) - into frames with a
+// zero margin: [kCellPad + nh + kCellPad rows][kCellPitch cells], pixel (y, x) at row y + kCellPad, cell
+// x + kCellPad; the margin is zeroed when the buffer is allocated and never written.
+template <bool CELLS>
 __global__ __launch_bounds__(256) void resize_u8_rows_kernel(
     const uint8_t* __restrict__ src, SampleArgs a, int64_t frame_stride, uint8_t* __restrict__ dst, int nh, int nw,
-    int row_bytes_padded) {
+    int row_bytes_padded, int chan_order) {
     extern __shared__ __attribute__((aligned(16))) uint8_t rows[];   // [2][row_bytes_padded]
     const int tid = threadIdx.x;
     const int y = blockIdx.x % nh;
@@ -171,7 +176,17 @@ __global__ __launch_bounds__(256) void resize_u8_rows_kernel(
                 v[cc] = min(max(t, 0), 255);
             }
         }
-        for (int cc = 0; cc < 3; ++cc) out[3 * x + cc] = (uint8_t)v[cc];
+        if constexpr (CELLS) {
+            const bool bgr = chan_order == CD_BGR;
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t rg = {(__bf16)(float)v[bgr ? 2 : 0], (__bf16)(float)v[1]};
+            const bf16x2_t b0 = {(__bf16)(float)v[bgr ? 0 : 2], (__bf16)0.f};
+            uint2* cells = reinterpret_cast<uint2*>(dst) +
+                           ((int64_t)f * (nh + 2 * kCellPad) + y + kCellPad) * kCellPitch + kCellPad;
+            cells[x] = uint2{__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, b0)};
+        } else {
+            for (int cc = 0; cc < 3; ++cc) out[3 * x + cc] = (uint8_t)v[cc];
+        }
     }
 }
 
@@ -193,10 +208,28 @@ int launch_resize_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int 
     const int padded = (W0 * 3 + 15) & ~15;
     dim3 grid((unsigned)(n * nh)), block(256);
     if (aligned && 2 * padded <= 64 * 1024)
-        hipLaunchKernelGGL(resize_u8_rows_kernel, grid, block, (size_t)2 * padded, s, src, a, frame_stride, dst, nh, nw,
-                           padded);
+        hipLaunchKernelGGL(resize_u8_rows_kernel<false>, grid, block, (size_t)2 * padded, s, src, a, frame_stride, dst, nh,
+                           nw, padded, 0);
     else
         hipLaunchKernelGGL(resize_u8_generic_kernel, grid, block, 0, s, src, a, frame_stride, dst, nh, nw);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
+}
+
+// The resize with operand cells as output (see resize_u8_rows_kernel<true>); `cells` points at the first
+// frame of the batch inside a buffer laid out by cell_frame_bytes().  Needs 16-byte aligned source rows
+// that fit the kernel's LDS (the caller checks with resize_cells_supported).
+bool resize_cells_supported(const uint8_t* src, int W0, int64_t row_stride, int64_t frame_stride, int nw) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
+    return aligned && 2 * ((W0 * 3 + 15) & ~15) <= 64 * 1024 && nw == kNetW;
+}
+
+int launch_resize_cells(const cd_handle* h, const uint8_t* src, int n, int H0, int W0, int64_t row_stride,
+                        int64_t frame_stride, int chan_order, uint8_t* cells, int nh, int nw, hipStream_t s) {
+    SampleArgs a{h->rt_pre.sx, h->rt_pre.ax, h->rt_pre.sy, h->rt_pre.by, h->rt_pre.mode, H0, W0, row_stride, 0, 0, 0, 0, 0};
+    const int padded = (W0 * 3 + 15) & ~15;
+    hipLaunchKernelGGL(resize_u8_rows_kernel<true>, dim3((unsigned)(n * nh)), dim3(256), (size_t)2 * padded, s, src, a,
+                       frame_stride, cells, nh, nw, padded, chan_order);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }
