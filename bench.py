@@ -54,7 +54,7 @@ BATCH = 256
 H0, W0 = 720, 1280
 SEED = 1234
 GAME_FRAMES = 200_000                      # the full-game shape of the strong-scaling leg
-C4 = dict(height=1080, width=1920, batch=512, frames=4096, dtype="bf16_split")     # the 1080p bf16 configuration
+C4 = dict(height=1080, width=1920, batch=512, frames=16384, dtype="bf16_split")     # the 1080p bf16 configuration
 
 # algorithmic work per frame, independent of the source resolution (2 flops per MAC):
 #   block 1: 144*256 px * 48 ch * 27 ; block 2: 48*85 * 48 * 432 ; block 3: 16*28 * 48 * 432 ; FC 768*32 + 32*3

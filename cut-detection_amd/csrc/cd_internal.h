@@ -104,6 +104,7 @@ struct Workspace {
 struct cd_handle {
     int device;
     int dtype;
+    int opt[CD_OPT_COUNT];     // cd_set_option
     cd::DeviceParams p;
     cd::ResizeTables rt;       // tables of the fused forward (cd_forward_u8 and its variants)
     cd::ResizeTables rt_pre;   // tables of the stand-alone kernels (cd_preprocess, cd_resize_u8): a caller that
@@ -125,6 +126,7 @@ struct cd_handle {
     size_t small_bytes;     // bytes of one of the three slots
     uint8_t* cells;         // split bf16: operand-cell frames of up to three batches in flight (see kCellPad)
     size_t cells_bytes;     // bytes of one of the three slots ((frames + 1) x cell_frame_bytes)
+    unsigned* tickets;      // [2048] role tickets of the fused kernel's workgroups, one counter per (CU, SIMD)
     int cells_h;            // network input height the cell frames' zero margins are laid out for
     int64_t* rle_blocks;    // workspace of cd_rle: per-block boundary counts / offsets
     double* rle_sums;       // ... and per-block fp64 sums of the maxima (same number of entries)

@@ -394,20 +394,11 @@ bool resize_is_point_sample(int H0, int W0, int nh, int nw) {
     return point;
 }
 
-// How cd_forward_u8_range spreads a range over its streams: 0 = whole batches alternate between two
-// streams, 1 = block 1 of every batch on one stream and blocks 2 + 3 on the other.  CUTDET_RANGE_MODE
-// overrides the default (for measurements); both give the same bits.
-int range_mode(const cd_handle* h) {
-    static const int forced = [] { const char* e = std::getenv("CUTDET_RANGE_MODE"); return e ? std::atoi(e) : -1; }();
-    if (forced == 0 || forced == 1) return forced;
-    (void)h;
-    return 0;
-}
-
-// CUTDET_FUSED12=0 keeps split-bf16 ranges on the separate block-1 and block-2 kernels (for measurements)
-bool fused12_enabled() {
-    static const bool on = [] { const char* e = std::getenv("CUTDET_FUSED12"); return !(e && e[0] == '0'); }();
-    return on;
+// Defaults of the per-handle options of cd_forward_u8_range (cd_set_option), from the environment:
+// CUTDET_RANGE_MODE (0 / 1), CUTDET_FUSED12 (0 / 1), CUTDET_RANGE_ONE_STREAM (0 / 1).
+int env_option(const char* name, int fallback) {
+    const char* e = std::getenv(name);
+    return e && (e[0] == '0' || e[0] == '1') && !e[1] ? e[0] - '0' : fallback;
 }
 
 // Streams and events of cd_forward_u8_range, created on first use (with the handle's device current).
@@ -482,6 +473,9 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     if (!h) { set_error("cd_create: out of host memory"); return CD_ENOMEM; }
     h->device = device;
     h->dtype = dtype;
+    h->opt[CD_OPT_RANGE_BY_STAGE] = env_option("CUTDET_RANGE_MODE", 0);
+    h->opt[CD_OPT_FUSE_BLOCKS12] = env_option("CUTDET_FUSED12", 0);
+    h->opt[CD_OPT_RANGE_ONE_STREAM] = env_option("CUTDET_RANGE_ONE_STREAM", 0);
     ParamOffsets off;
     std::vector<float> img = pack_params(f.data(), &off);
     auto fail = [&](int code) { cd_destroy(h); return code; };
@@ -510,6 +504,8 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->rle_blocks_cap = 1 << 16;   // x 4096 frames per block
     CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->rle_blocks), (size_t)h->rle_blocks_cap * sizeof(int64_t)));
     CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->rle_sums), (size_t)h->rle_blocks_cap * sizeof(double)));
+    CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->tickets), 2048 * sizeof(unsigned)));
+    CD_TRY(hipMemset(h->tickets, 0, 2048 * sizeof(unsigned)));
 #undef CD_TRY
     if (init_conv3_head() != CD_OK) return fail(CD_EHIP);
     if (init_static_scratch(device) != CD_OK) return fail(CD_EHIP);
@@ -536,6 +532,7 @@ void cd_destroy(cd_handle* h) {
         if (e) (void)hipEventDestroy(e);
     if (h->rle_blocks) (void)hipFree(h->rle_blocks);
     if (h->rle_sums) (void)hipFree(h->rle_sums);
+    if (h->tickets) (void)hipFree(h->tickets);
     for (int st = 0; st < CD_STAGE_COUNT; ++st) {
         for (hipEvent_t e : h->ev_start[st]) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->ev_stop[st]) (void)hipEventDestroy(e);
@@ -703,7 +700,7 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     // geometry, and frames that already have the network's size, go straight into the fused block 1.
     // Split bf16: every geometry goes through the resize pass, which writes the first block's operand
     // cells, and blocks 1 + 2 run as one kernel whose block-1 activations stay in LDS.
-    const bool fused12 = h->dtype == CD_BF16_SPLIT && fused12_enabled() &&
+    const bool fused12 = h->dtype == CD_BF16_SPLIT && h->opt[CD_OPT_FUSE_BLOCKS12] &&
                          resize_cells_supported(src, W0, row_stride, frame_stride, net_w);
     const bool two_pass = fused12 || (!(H0 == net_h && W0 == net_w) && !resize_is_point_sample(H0, W0, net_h, net_w));
     if ((rc = ensure_range_state(h))) return rc;
@@ -749,28 +746,30 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     CD_HIP(hipStreamWaitEvent(h->side_cls, h->ev_fork, 0));
     if (two_pass) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_fork, 0));
     const int64_t small_row = (int64_t)net_w * 3, small_frame = small_row * net_h;
-    const int mode = fused12 ? 0 : range_mode(h);
+    const int mode = fused12 ? 0 : h->opt[CD_OPT_RANGE_BY_STAGE];
+    const bool one_stream = h->opt[CD_OPT_RANGE_ONE_STREAM] != 0;
+    hipStream_t pre = one_stream ? s : h->side_pre;
     for (int64_t i = 0; i < nb; ++i) {
         const int64_t a = i * batch;
         const int k = (int)std::min<int64_t>(batch, n - a);
         const int par = (int)(i & 1), slot = (int)(i % 3);
         // mode 0: the whole batch on one of two alternating streams.  mode 1: block 1 of every batch on the
         // side stream, blocks 2 and 3 on the caller's stream, handed over through the two workspaces.
-        hipStream_t st1 = mode == 1 ? h->side_cls : (par ? h->side_cls : s);
-        hipStream_t st2 = mode == 1 ? s : st1;
+        hipStream_t st1 = one_stream ? s : mode == 1 ? h->side_cls : (par ? h->side_cls : s);
+        hipStream_t st2 = one_stream || mode == 1 ? s : st1;
         const Workspace& ws = h->ws[par];
         const uint8_t* in = src + a * frame_stride;
         int fH = H0, fW = W0;
         int64_t frs = row_stride, ffs = frame_stride;
         if (fused12) {
             uint8_t* dst = h->cells + (size_t)slot * h->cells_bytes;
-            if (i >= 3) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot
+            if (i >= 3) CD_HIP(hipStreamWaitEvent(pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot
             {
-                StageTimer t(h, CD_STAGE_PREPROCESS, h->side_pre);
+                StageTimer t(h, CD_STAGE_PREPROCESS, pre);
                 if ((rc = launch_resize_cells(h, in, k, H0, W0, row_stride, frame_stride, chan_order, dst, net_h, net_w,
-                                              h->side_pre))) return rc;
+                                              pre))) return rc;
             }
-            CD_HIP(hipEventRecord(h->ev_ready[slot], h->side_pre));
+            CD_HIP(hipEventRecord(h->ev_ready[slot], pre));
             CD_HIP(hipStreamWaitEvent(st1, h->ev_ready[slot], 0));
             {   // blocks 1 + 2 in one kernel, timed as block 2
                 StageTimer t(h, CD_STAGE_CONV2, st1);
@@ -784,12 +783,12 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
         }
         if (two_pass) {
             uint8_t* dst = h->small + (size_t)slot * h->small_bytes;
-            if (i >= 3) CD_HIP(hipStreamWaitEvent(h->side_pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot
+            if (i >= 3) CD_HIP(hipStreamWaitEvent(pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot
             {
-                StageTimer t(h, CD_STAGE_PREPROCESS, h->side_pre);
-                if ((rc = launch_resize_u8(h, in, k, H0, W0, row_stride, frame_stride, dst, net_h, net_w, h->side_pre))) return rc;
+                StageTimer t(h, CD_STAGE_PREPROCESS, pre);
+                if ((rc = launch_resize_u8(h, in, k, H0, W0, row_stride, frame_stride, dst, net_h, net_w, pre))) return rc;
             }
-            CD_HIP(hipEventRecord(h->ev_ready[slot], h->side_pre));
+            CD_HIP(hipEventRecord(h->ev_ready[slot], pre));
             CD_HIP(hipStreamWaitEvent(st1, h->ev_ready[slot], 0));
             in = dst; fH = net_h; fW = net_w; frs = small_row; ffs = small_frame;
         }
@@ -812,6 +811,15 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     // join: everything this call queued anywhere is ordered before what the caller queues next
     CD_HIP(hipEventRecord(h->ev_join, h->side_cls));
     CD_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    return CD_OK;
+}
+
+int cd_set_option(cd_handle* h, int option, int value) {
+    if (!h || option < 0 || option >= CD_OPT_COUNT || (value != 0 && value != 1)) {
+        set_error("cd_set_option: option %d, value %d", option, value);
+        return CD_EINVAL;
+    }
+    h->opt[option] = value;
     return CD_OK;
 }
 

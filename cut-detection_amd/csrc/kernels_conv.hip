@@ -1374,37 +1374,32 @@ __device__ __forceinline__ void conv12_produce(const uint2* cin, uint32_t* pb, c
     };
     auto finish = [&](const f32x4 (&acc)[3][3], int r) {
         const float m[4] = {window_max<0>(acc), window_max<1>(acc), window_max<2>(acc), window_max<3>(acc)};
+        // rows and columns outside the frame are block 2's zero padding: a zero scale and shift for such a
+        // row (selects, so that the row's code stays one basic block the scheduler can interleave), a
+        // select per column
         const bool row_in = (unsigned)(Y0 + r) < (unsigned)H1;
+        const float scr = row_in ? sc : 0.f, shr = row_in ? sh : 0.f;
+        float v[4];
 #pragma unroll
         for (int wi = 0; wi < 4; ++wi) {
-            const int x = 4 * q + wi;
-            const bool in = row_in && (unsigned)(X0 + x) < (unsigned)kW1;
-            const float v = in ? fmaf(m[wi], sc, sh) : 0.f;
-            const uint32_t hi = pack_bf16(v, 0.f) & 0xFFFFu;
-            const uint32_t lo = pack_bf16(v - __uint_as_float(hi << 16), 0.f);
-            if (x < kP2) {
-                out[(r * kP2 + x) * 32] = (uint16_t)hi;
-                out[(r * kP2 + x) * 32 + 4] = (uint16_t)lo;
-            }
+            const bool in = (unsigned)(X0 + 4 * q + wi) < (unsigned)kW1;
+            v[wi] = in ? fmaf(m[wi], scr, shr) : 0.f;
+        }
+        // windows 14 and 15 of the row (lanes q = 3, wi = 2, 3) are not part of the patch: they write
+        // window 13's value to window 13's cell again instead of branching around the stores
+        const bool tail = q == 3;
+        v[2] = tail ? v[1] : v[2];
+        v[3] = tail ? v[1] : v[3];
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi) {
+            const int x = wi < 2 ? 4 * q + wi : (tail ? 13 : 4 * q + wi);
+            const uint32_t hi = pack_bf16(v[wi], 0.f) & 0xFFFFu;
+            const uint32_t lo = pack_bf16(v[wi] - __uint_as_float(hi << 16), 0.f);
+            out[(r * kP2 + x) * 32] = (uint16_t)hi;
+            out[(r * kP2 + x) * 32 + 4] = (uint16_t)lo;
         }
     };
-    u32x4 a[5][3];
-#pragma unroll
-    for (int rr = 0; rr < 5; ++rr)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) a[rr][j] = cell(rr, j);
-    f32x4 prev[3][3];
-#pragma unroll
-    for (int r = 0; r < kP2; ++r) {
-        // the three new input rows of the next patch row are requested before this row's MFMAs
-        u32x4 nx[3][3];
-        if (r + 1 < kP2) {
-#pragma unroll
-            for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) nx[rr][j] = cell(3 * (r + 1) + 2 + rr, j);
-        }
-        f32x4 acc[3][3];
+    auto mfmas = [&](const u32x4 (&a)[5][3], f32x4 (&acc)[3][3]) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1414,43 +1409,86 @@ __device__ __forceinline__ void conv12_produce(const uint2* cin, uint32_t* pb, c
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t + ky][j]),
                                                                         __builtin_bit_cast(bf16x8, bw[ky][G]),
                                                                         ky == 0 ? bias4 : acc[t][j], 0, 0, 0);
-        // the previous row's pooling / affine / split / LDS writes are independent of these MFMAs
-        if (r > 0) finish(prev, r - 1);
+    };
+    // Scheduling pattern of one patch row: its 27 MFMAs with, behind each, a share of the other row's
+    // pooling / affine / split arithmetic and of the LDS traffic (the next row's cell reads early, the
+    // other row's result writes late).  Left to itself the compiler issues the MFMAs back to back and
+    // the vector work after them, and the wave does one thing at a time.
+    auto interleave = [&]() {
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int k = 0; k < 27; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+            if (k < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                 // four vector instructions
+            if (k >= 16 && k < 24) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one LDS write
+        }
+    };
+    u32x4 a[5][3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) prev[t][j] = acc[t][j];
+    for (int rr = 0; rr < 5; ++rr)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[rr][j] = cell(rr, j);
+    // Two patch rows per iteration, each with accumulators of its own: a row's pooling / affine / split
+    // / LDS writes are independent of the other row's MFMAs and are scheduled among them.
+    f32x4 acc0[3][3], acc1[3][3];
+    auto advance = [&](int r) {          // a <- the five input rows of patch row r + 1
+        u32x4 nx[3][3];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) nx[rr][j] = cell(3 * (r + 1) + 2 + rr, j);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             a[0][j] = a[3][j]; a[1][j] = a[4][j];
-            if (r + 1 < kP2) { a[2][j] = nx[0][j]; a[3][j] = nx[1][j]; a[4][j] = nx[2][j]; }
+            a[2][j] = nx[0][j]; a[3][j] = nx[1][j]; a[4][j] = nx[2][j];
         }
-        // (a row's loads, MFMAs and the previous row's epilogue are scheduled together, but not
-        // across rows: left free, the compiler requests every row's cells at once and spills)
+    };
+#pragma unroll
+    for (int r = 0; r < kP2; r += 2) {
+        // (sched_barrier: scheduling stays within a row; left free across rows, the compiler requests
+        // every row's cells at once and spills)
+        mfmas(a, acc0);
+        if (r > 0) finish(acc1, r - 1);
+        advance(r);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a, acc1);
+        finish(acc0, r);
+        if (r + 2 < kP2) advance(r + 1);
+        interleave();
         __builtin_amdgcn_sched_barrier(0);
     }
-    finish(prev, kP2 - 1);
+    finish(acc1, kP2 - 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
-// byte offset of lane's piece of wave-wide copy `it` of a tile's input cells (22 pieces per 44-cell row;
-// pieces past the last row re-read it and land behind the cells in LDS)
+// byte offset of lane's piece of wave-wide copy `it` of a tile's input cells (22 pieces per 44-cell row)
 __device__ __forceinline__ int conv12_in_rel(int it, int lane) {
     const int f = it * 64 + lane, row = min(f / 22, kFIn - 1), pc = f % 22;
     return row * (kCellPitch * 8) + pc * 16;
 }
 
-// consume(G): conv2_unit on a patch that is complete when it starts.  Weight fragments are requested
-// two steps ahead across units and tiles as in conv2_kernel; the A operands of a unit's first step are
-// read at its start (the patch did not exist earlier).  In the last unit of a tile the copies of the
-// next tile's input cells are dealt out behind step 0's operand loads.
+// LDS-DMA of a tile's 44 x 44 input cells: 15 full wave-wide copies and one of 8 lanes
+__device__ __forceinline__ void conv12_copy_cells(const char* src, char* cin_lds, const int (&rel)[kFInDma], int lane) {
+#pragma unroll
+    for (int it = 0; it < kFInDma; ++it) {
+        if (it < kFInDma - 1 || lane < kFInPieces - 64 * (kFInDma - 1))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)rel[it]),
+                                             (__attribute__((address_space(3))) void*)(cin_lds + it * 1024), 16, 0, 0);
+    }
+}
+
+// consume(G): the 9 steps x 54 MFMAs of one channel group of a block-2 wave tile on a patch that is
+// complete in LDS.  The operands of the next step (nine LDS reads, three weight fragments through the
+// buffer descriptor) are requested one per MFMA during the current step; the A operands of a unit's
+// first step are read at its start (the patch did not exist earlier), its weights were requested
+// during the previous unit's last step.
 template <int G>
 __device__ __forceinline__ void conv12_consume(const uint32_t* pb, const int (&base)[3], __amdgpu_buffer_rsrc_t wr,
-                                               int lane, u32x4 (&a)[2][3][3], SplitB (&b)[3][3], f32x4 (&acc)[3][3][3],
-                                               const char* next_cells, char* cin_lds) {
-    constexpr int kM = 54, kBD = 2, kNB = 3, kFirst = G * 9;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kBD - 1) * 6) : "memory");
+                                               int lane, u32x4 (&a)[2][3][3], SplitB (&b)[2][3], f32x4 (&acc)[3][3][3]) {
+    constexpr int kM = 54, kFirst = G * 9;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     constexpr int c0 = kFirst & 1;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -1459,32 +1497,24 @@ __device__ __forceinline__ void conv12_consume(const uint32_t* pb, const int (&b
 #pragma unroll
     for (int kk = 0; kk < 9; ++kk) {
         const int c = (kFirst + kk) & 1;
-        const int bc = (kFirst + kk) % kNB, bn = (kFirst + kk + kBD) % kNB;
-        const int bstep = (kFirst + kk + kBD) % 27, bg = bstep / 9, bk = bstep % 9;
+        const int bstep = (kFirst + kk + 1) % 27, bg = bstep / 9, bk = bstep % 9;
         const int nk = kk + 1;
         const int off = ((nk / 3) * kP2 + (nk % 3)) * 16;
-        const int n_ops = kk < 8 ? 12 : 3;
-        const int n_side = n_ops + (G == 2 && kk == 0 ? kFInDma : 0);
-        static_assert(12 + kFInDma <= kM, "more memory instructions than MFMAs in a step");
+        const int n_side = kk < 8 ? 12 : 3;
 #pragma unroll
         for (int m = 0; m < kM; ++m) {
             const int e = m / 27, t = (m / 9) % 3, j = (m / 3) % 3, nt = m % 3;
             if (G == 0 && kk == 0 && e == 0)
-                acc[t][j][nt] = mfma_frag<kS2>(a[c][t][j], b[bc][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
+                acc[t][j][nt] = mfma_frag<kS2>(a[c][t][j], b[c][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
             else
-                acc[t][j][nt] = mfma_frag<kS2>(a[c][t][j], b[bc][nt], e, acc[t][j][nt]);
+                acc[t][j][nt] = mfma_frag<kS2>(a[c][t][j], b[c][nt], e, acc[t][j][nt]);
             if (m < n_side) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (m < 3) {
-                    b[bn][m] = load_frag<kS2>(wr, lane, (bk * 3 + bg) * 3 + m);
-                } else if (m < n_ops) {
+                    b[c ^ 1][m] = load_frag<kS2>(wr, lane, (bk * 3 + bg) * 3 + m);
+                } else {
                     const int lt = (m - 3) / 3, lj = (m - 3) % 3;
                     a[c ^ 1][lt][lj] = *reinterpret_cast<const u32x4*>(pb + base[lj] + off + lt * kP2 * 16);
-                } else {
-                    const int it = m - n_ops;
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(next_cells + (uint32_t)conv12_in_rel(it, lane)),
-                        (__attribute__((address_space(3))) void*)(cin_lds + it * 1024), 16, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1493,16 +1523,37 @@ __device__ __forceinline__ void conv12_consume(const uint32_t* pb, const int (&b
     }
 }
 
-__global__ __launch_bounds__(64) void conv12_split_kernel(const uint8_t* __restrict__ cells, uint32_t* __restrict__ out,
-                                                          const u32x4* __restrict__ w1, const float* __restrict__ post1,
-                                                          const void* __restrict__ w2, const float* __restrict__ post2,
-                                                          int n, int H, int H1, int Hp, int tiles_x, int tiles_y,
-                                                          int total_tiles) {
+// Workgroup = two waves with two jobs: wave 0 produces the patches (block 1), wave 1 consumes them
+// (block 2).  Step S of a workgroup: the producer writes channel group S % 3 of tile S / 3 into patch
+// buffer S & 1 while the consumer works on the group written in step S - 1; a workgroup barrier ends
+// the step.  Two waves per SIMD (256 registers each): one wave's pooling arithmetic, LDS traffic and
+// waits run in the shadow of the other's MFMAs.
+__global__ __launch_bounds__(128, 2) void conv12_split_kernel(const uint8_t* __restrict__ cells, uint32_t* __restrict__ out,
+                                                              const u32x4* __restrict__ w1, const float* __restrict__ post1,
+                                                              const void* __restrict__ w2, const float* __restrict__ post2,
+                                                              int n, int H, int H1, int Hp, int tiles_x, int tiles_y,
+                                                              int total_tiles, unsigned* __restrict__ tickets) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kFLds];
     uint2* cin = reinterpret_cast<uint2*>(lds);
     uint32_t* pb0 = reinterpret_cast<uint32_t*>(lds + kFInBytes);
-    uint32_t* pb1 = pb0 + kFPatchElems;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // Which wave produces.  The dispatcher deals the waves of a CU's workgroups round the SIMDs in a
+    // fixed order, so with four of these workgroups on a CU the first waves of two of them share one
+    // SIMD and their second waves another: "wave 0 produces" would put two producers on one SIMD and
+    // two consumers on the other.  Every workgroup therefore takes a ticket from a counter of its
+    // (CU, SIMD of wave 0): the parity of the ticket swaps the roles in every second workgroup there,
+    // and each SIMD gets one producer (vector arithmetic + short MFMA bursts) beside one consumer
+    // (MFMAs back to back).  Only the balance depends on this; any assignment is correct.
+    __shared__ int flip_lds;
+    if (threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned slot = ((xcc & 7u) << 8) | (((hw >> 13) & 3u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
+        flip_lds = (int)(atomicAdd(tickets + slot, 1u) & 1u);
+    }
+    __syncthreads();
+    const bool producer = (threadIdx.x < 64) != (flip_lds != 0);
     const int per_frame = tiles_x * tiles_y;
     const int64_t in_frame = (int64_t)(H + 2 * kCellPad) * kCellPitch * 8, out_frame = (int64_t)(Hp + 2) * kP2W * kC;
     auto valid = [&](int id) {
@@ -1511,89 +1562,131 @@ __global__ __launch_bounds__(64) void conv12_split_kernel(const uint8_t* __restr
         return id < total_tiles && frame < n;
     };
     struct Tile { const char* src; uint32_t* dst; int ty, tx; };
-    // invalid ids map to tile 0 of frame 0, so that the last look-ahead copy of a wave stays in bounds
     auto locate = [&](int id) {
         int frame = 0, tt = 0;
-        if (valid(id)) xcd_frame_tile(id, per_frame, frame, tt);
+        xcd_frame_tile(id, per_frame, frame, tt);
         Tile t;
         t.ty = tt / tiles_x; t.tx = tt % tiles_x;
         t.src = reinterpret_cast<const char*>(cells) + frame * in_frame + ((int64_t)(36 * t.ty) * kCellPitch + 36 * t.tx) * 8;
         t.dst = out + frame * out_frame;
         return t;
     };
+    // Both waves walk the same tiles (ids blockIdx.x, + gridDim.x, ...: validity only ever goes from
+    // true to false along that sequence, frames being dealt to ids in increasing order) and execute
+    // the same number of barriers: one per step, plus the consumer's lead-in / the producer's lead-out.
     int id = blockIdx.x;
     if (!valid(id)) return;
-
     const int i = lane & 15, kq = lane >> 4;
-    int base[3], cbase[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * 16 + 4 * kq;
-        const int c12 = 4 * j + (i & 3), d = (c12 * 11) >> 5, m = c12 - 3 * d;      // d = c12 / 3
-        const int W = min(4 * (i >> 2) + d, kP2 - 1);
-        // (lanes kq = 3 carry zero weights; they re-read the kq = 2 cell)
-        cbase[j] = 3 * W + m + min(kq, 2);
-    }
-    const __amdgpu_buffer_rsrc_t wr = weight_rsrc<kS2>(w2);
-    // block-1 weight fragments (ky, n-tile) and both blocks' bias / BatchNorm terms stay in registers
-    u32x4 bw[3][3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int nt = 0; nt < 3; ++nt) bw[ky][nt] = w1[(ky * 3 + nt) * 64 + lane];
-    float p1[3][3];
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p1[nt][k] = post1[k * kC + nt * 16 + (lane & 15)];
+#ifdef CD_DIAG12
+    // diagnostic build: per-wave time stamps of the second and third tile go to the slack frame behind the batch
+    unsigned long long* st12 = reinterpret_cast<unsigned long long*>(out + (int64_t)n * out_frame) + (blockIdx.x * 2 + (producer ? 0 : 1)) * 24;
+    int tile_no = 0;
+#define CD12_STAMP(k) do { if (lane == 0 && blockIdx.x < 256 && tile_no >= 1 && tile_no <= 2) st12[(tile_no - 1) * 12 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CD12_NEXT() (++tile_no)
+#else
+#define CD12_STAMP(k) do { } while (0)
+#define CD12_NEXT() do { } while (0)
+#endif
 
-    Tile cur = locate(id);
-    int next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
-    Tile nxt = locate(next_id);
-    u32x4 a[2][3][3];
-    SplitB b[3][3];
-    f32x4 acc[3][3][3];
+    if (producer) {
+        int cbase[3];
 #pragma unroll
-    for (int it = 0; it < kFInDma; ++it)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cur.src + (uint32_t)conv12_in_rel(it, lane)),
-                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(lds) + it * 1024),
-                                         16, 0, 0);
-    // weight fragments of the first two steps (step s of a tile = kernel tap s % 9 of channel group s / 9)
+        for (int j = 0; j < 3; ++j) {
+            const int c12 = 4 * j + (i & 3), d = (c12 * 11) >> 5, m = c12 - 3 * d;      // d = c12 / 3
+            const int W = min(4 * (i >> 2) + d, kP2 - 1);
+            // (lanes kq = 3 carry zero weights; they re-read the kq = 2 cell)
+            cbase[j] = 3 * W + m + min(kq, 2);
+        }
+        // block-1 weight fragments (ky, n-tile) and its bias / BatchNorm terms stay in registers
+        u32x4 bw[3][3];
 #pragma unroll
-    for (int s0 = 0; s0 < 2; ++s0)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) b[s0][nt] = load_frag<kS2>(wr, lane, ((s0 % 9) * 3 + s0 / 9) * 3 + nt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    for (;;) {
-        // the input cells of this tile (copied during the previous tile's last unit) have landed:
-        // VMEM completes in issue order and only weight loads were issued after the copies
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const int Y0 = 12 * cur.ty - 1, X0 = 12 * cur.tx - 1;
-#pragma unroll
-        for (int s0 = 0; s0 < 2; ++s0)
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt) { asm volatile("" : "+v"(b[s0][nt].h)); asm volatile("" : "+v"(b[s0][nt].l)); }
-        conv12_produce<0>(cin, pb1, bw, p1, cbase, lane, Y0, X0, H1);
-        conv12_consume<0>(pb1, base, wr, lane, a, b, acc, nxt.src, reinterpret_cast<char*>(lds));
-        conv12_produce<1>(cin, pb0, bw, p1, cbase, lane, Y0, X0, H1);
-        conv12_consume<1>(pb0, base, wr, lane, a, b, acc, nxt.src, reinterpret_cast<char*>(lds));
-        conv12_produce<2>(cin, pb1, bw, p1, cbase, lane, Y0, X0, H1);
-        // block 2's bias / BatchNorm terms are only needed by the epilogue: requested here (older than
-        // every load the last unit issues, so its waits cover them), they do not occupy registers
-        // during the produce phases
-        float p2[3][3];
+            for (int nt = 0; nt < 3; ++nt) bw[ky][nt] = w1[(ky * 3 + nt) * 64 + lane];
+        float p1[3][3];
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) p2[nt][k] = post2[k * kC + nt * 16 + (lane & 15)];
-        // every read of the input cells is done (their values fed MFMAs that have issued): the next
-        // tile's cells may overwrite them, which consume<2> starts in its first step
-        conv12_consume<2>(pb1, base, wr, lane, a, b, acc, nxt.src, reinterpret_cast<char*>(lds));
-        // pooled + normalised results -> HBM, transposed through the patch buffer just consumed
+            for (int k = 0; k < 3; ++k) p1[nt][k] = post1[k * kC + nt * 16 + (lane & 15)];
+        int rel[kFInDma];
+#pragma unroll
+        for (int it = 0; it < kFInDma; ++it) rel[it] = conv12_in_rel(it, lane);
+        Tile cur = locate(id);
+        conv12_copy_cells(cur.src, reinterpret_cast<char*>(lds), rel, lane);
+        int par = 0;                      // patch buffer of the next group
+        for (;;) {
+            CD12_STAMP(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's input cells have landed
+            CD12_STAMP(1);
+            const int Y0 = 12 * cur.ty - 1, X0 = 12 * cur.tx - 1;
+            conv12_produce<0>(cin, pb0 + par * kFPatchElems, bw, p1, cbase, lane, Y0, X0, H1);
+            CD12_STAMP(2);
+            __builtin_amdgcn_s_barrier();
+            CD12_STAMP(3);
+            par ^= 1;
+            conv12_produce<1>(cin, pb0 + par * kFPatchElems, bw, p1, cbase, lane, Y0, X0, H1);
+            CD12_STAMP(4);
+            __builtin_amdgcn_s_barrier();
+            CD12_STAMP(5);
+            par ^= 1;
+            conv12_produce<2>(cin, pb0 + par * kFPatchElems, bw, p1, cbase, lane, Y0, X0, H1);
+            CD12_STAMP(6);
+            par ^= 1;
+            // every read of the input cells is done (produce ends with an LDS wait): the next tile's
+            // cells may replace them
+            const int next_id = id + (int)gridDim.x;
+            const bool more = valid(next_id);
+            if (more) {
+                id = next_id;
+                cur = locate(id);
+                conv12_copy_cells(cur.src, reinterpret_cast<char*>(lds), rel, lane);
+            }
+            CD12_STAMP(7);
+            __builtin_amdgcn_s_barrier();
+            CD12_STAMP(8);
+            CD12_NEXT();
+            if (!more) break;
+        }
+        __builtin_amdgcn_s_barrier();          // the consumer's last step
+        return;
+    }
+
+    // ---- consumer
+    int base[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * 16 + 4 * kq;
+    const __amdgpu_buffer_rsrc_t wr = weight_rsrc<kS2>(w2);
+    float p2[3][3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p2[nt][k] = post2[k * kC + nt * 16 + (lane & 15)];
+    u32x4 a[2][3][3];
+    SplitB b[2][3];
+    f32x4 acc[3][3][3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) b[0][nt] = load_frag<kS2>(wr, lane, nt);      // step 0: tap 0 of channel group 0
+    int par = 0;
+    __builtin_amdgcn_s_barrier();              // the producer's first step
+    for (;;) {
+        const Tile cur = locate(id);
+        CD12_STAMP(0);
+        conv12_consume<0>(pb0 + par * kFPatchElems, base, wr, lane, a, b, acc);
+        CD12_STAMP(1);
+        __builtin_amdgcn_s_barrier();
+        CD12_STAMP(2);
+        par ^= 1;
+        conv12_consume<1>(pb0 + par * kFPatchElems, base, wr, lane, a, b, acc);
+        CD12_STAMP(3);
+        __builtin_amdgcn_s_barrier();
+        CD12_STAMP(4);
+        par ^= 1;
+        conv12_consume<2>(pb0 + par * kFPatchElems, base, wr, lane, a, b, acc);
+        CD12_STAMP(5);
+        // pooled + normalised results -> HBM, transposed through the patch buffer just consumed (the
+        // producer is writing the other one; it gets this one back at the barrier below)
         {
-            float* scratch = reinterpret_cast<float*>(pb1);
+            float* scratch = reinterpret_cast<float*>(pb0 + par * kFPatchElems);
             const int q = lane >> 4, ch = lane & 15;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -1618,15 +1711,20 @@ __global__ __launch_bounds__(64) void conv12_split_kernel(const uint8_t* __restr
                     *reinterpret_cast<u32x4*>(cur.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = split_bf16(v);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
         }
-        if (next_id < 0) break;
+        par ^= 1;
+        // 27 steps leave the next step's weights (tap 0 of group 0 again) in set 1; a tile starts from set 0
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) b[0][nt] = b[1][nt];
+        const int next_id = id + (int)gridDim.x;
+        const bool more = valid(next_id);
+        CD12_STAMP(6);
+        __builtin_amdgcn_s_barrier();
+        CD12_STAMP(7);
+        CD12_NEXT();
+        if (!more) break;
         id = next_id;
-        cur = nxt;
-        next_id = valid(id + (int)gridDim.x) ? id + (int)gridDim.x : -1;
-        nxt = locate(next_id);
     }
-    // the look-ahead copy and weight loads of a tile that will never run are still in flight
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
@@ -1635,9 +1733,9 @@ int launch_conv12_split(const cd_handle* h, const Workspace& ws, const uint8_t* 
     const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
     const int total = (int)xcd_grid(n, tiles_x * tiles_y);
     const int grid = total < 1024 ? total : 1024;
-    hipLaunchKernelGGL(conv12_split_kernel, dim3((unsigned)grid), dim3(64), 0, s, cells, reinterpret_cast<uint32_t*>(ws.act2),
+    hipLaunchKernelGGL(conv12_split_kernel, dim3((unsigned)grid), dim3(128), 0, s, cells, reinterpret_cast<uint32_t*>(ws.act2),
                        reinterpret_cast<const u32x4*>(h->p.w1s), (const float*)h->p.post, (const void*)h->p.w2s,
-                       h->p.post + 3 * kC, n, g.h, g.h1, g.h2, tiles_x, tiles_y, total);
+                       h->p.post + 3 * kC, n, g.h, g.h1, g.h2, tiles_x, tiles_y, total, h->tickets);
     CD_HIP(hipGetLastError());
     return CD_OK;
 }

@@ -22,6 +22,7 @@ CD_BF16 = 1
 CD_BF16_SPLIT = 2
 DTYPES = {"f32": CD_F32, "bf16": CD_BF16, "bf16_split": CD_BF16_SPLIT}
 CD_BGR, CD_RGB = 0, 1
+OPTIONS = {"range_by_stage": 0, "fuse_blocks12": 1, "range_one_stream": 2}
 STAGES = ("preprocess", "conv1", "conv2", "conv3_head", "rle")
 
 _h = C.c_void_p
@@ -41,6 +42,7 @@ SIGNATURES = {
     "cd_forward": (C.c_int, [_h, _p, _i, _i, _i, _p, _p, _p, _p]),
     "cd_forward_u8": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),
     "cd_forward_u8_range": (C.c_int, [_h, _p, _l, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),
+    "cd_set_option": (C.c_int, [_h, _i, _i]),
     "cd_forward_u8_static": (C.c_int, [_h, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _p, _p, _p]),
     "cd_max_argmax": (C.c_int, [_h, _p, _l, _i, _p, _p, _p]),
     "cd_eval_accumulate": (C.c_int, [_h, _p, _p, _l, _i, _p, _p, _p, _p]),

@@ -84,6 +84,11 @@ class Engine:
         n, H0, W0, _ = frames.shape
         return n, H0, W0, frames.stride(1), frames.stride(0) if n > 1 else max(frames.stride(0), frames.stride(1) * H0)
 
+    def set_option(self, name, value):
+        """Scheduling options of forward_u8_range (cd_set_option): "range_by_stage", "fuse_blocks12",
+        "range_one_stream"; value 0 or 1.  Every setting gives the same bits."""
+        check(lib.cd_set_option(self._h, _lib.OPTIONS[name], int(bool(value))))
+
     def reserve(self, max_frames, net_h=144):
         check(lib.cd_reserve(self._h, int(max_frames), int(net_h)))
 

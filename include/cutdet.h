@@ -165,6 +165,22 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
                         int net_h, int net_w,
                         float* logits, float* maxv, int64_t* argmax, void* stream);
 
+/* How cd_forward_u8_range schedules its work; every setting gives the same bits.  No counterpart in the
+ * reference.  The defaults can also be set through the environment when a handle is created
+ * (CUTDET_RANGE_MODE, CUTDET_FUSED12, CUTDET_RANGE_ONE_STREAM = 0 or 1).
+ *   CD_OPT_RANGE_BY_STAGE   0 (default): whole batches alternate between the two streams.  1: block 1
+ *                           of every batch on one stream, blocks 2 + 3 on the other.
+ *   CD_OPT_FUSE_BLOCKS12    CD_BF16_SPLIT handles only.  1: the resize pass writes the first block's
+ *                           bfloat16 operand cells and blocks 1 + 2 run as ONE kernel whose block-1
+ *                           activations stay in LDS (no 835 KB per frame written to and read back from
+ *                           HBM).  0 (default): separate kernels, which is the faster of the two on the
+ *                           measured geometries - the fused kernel fills every CU's registers and LDS,
+ *                           so nothing overlaps with it.
+ *   CD_OPT_RANGE_ONE_STREAM 1: everything on the caller's stream (for measurements: per-stage event
+ *                           times are then the kernels' own durations). */
+enum { CD_OPT_RANGE_BY_STAGE = 0, CD_OPT_FUSE_BLOCKS12 = 1, CD_OPT_RANGE_ONE_STREAM = 2, CD_OPT_COUNT = 3 };
+int cd_set_option(cd_handle* h, int option, int value);
+
 /* cd_forward_u8 for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
  * and results as cd_forward_u8 (bit-identical), but the activations between the blocks live in a

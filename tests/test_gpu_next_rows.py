@@ -349,6 +349,41 @@ def test_range_entry_matches_single_batch_calls(dtype):
     assert same
 
 
+@pytest.mark.parametrize("h,w,bs,n", [(720, 1280, 96, 500), (1080, 1920, 64, 200), (180, 320, 50, 333), (480, 640, 40, 90)])
+def test_fused_blocks_1_and_2_give_the_bits_of_the_separate_kernels(h, w, bs, n):
+    """Split bf16 with CD_OPT_FUSE_BLOCKS12: the resize pass writes operand cells and blocks 1 + 2 run as
+    one kernel (producer and consumer waves, block-1 activations in LDS).  Logits, maxima and classes
+    must equal the per-batch calls' bit for bit: point-sampling and bilinear geometries, a 4:3 frame
+    (192 network rows: other tile counts and frame margins), short last batches, repeated calls."""
+    from cutdet import api, synth as csynth
+    from cutdet.engine import Engine
+    from cutdet.pipeline import ClipClassifier
+    base = api.default_engine("cuda:0", "bf16_split")
+    eng = Engine(api.default_blob(), base.device, "bf16_split")
+    eng.set_option("fuse_blocks12", 1)
+    cl = csynth.classes_from_runs(csynth.run_table(n, SEED))
+    frames = base.synth_frames(torch.tensor(cl, dtype=torch.uint8, device=base.device), h, w, SEED)
+    want = ClipClassifier(base, n)
+    want.classify_range(frames, 0, bs, overlap=False)
+    got = ClipClassifier(eng, n)
+    for _ in range(2):
+        got.logits.fill_(float("nan"))
+        got.classify_range(frames, 0, bs)
+        assert torch.equal(got.logits, want.logits) and torch.equal(got.cls, want.cls) and torch.equal(got.maxv, want.maxv)
+    assert got.cls.cpu().tolist() == cl
+    # the other schedules of the range entry on the same handle
+    for opt in ("range_one_stream", "range_by_stage"):
+        eng.set_option("fuse_blocks12", 0)
+        eng.set_option(opt, 1)
+        got.logits.fill_(float("nan"))
+        got.classify_range(frames, 0, bs)
+        assert torch.equal(got.logits, want.logits), opt
+        eng.set_option(opt, 0)
+    from cutdet import _lib
+    assert _lib.lib.cd_set_option(eng._h, 9, 1) == _lib.CD_EINVAL and _lib.lib.cd_set_option(eng._h, 1, 2) == _lib.CD_EINVAL
+    eng.close()
+
+
 def test_range_entry_rejects_bad_arguments(engine):
     from cutdet._lib import CutdetError
     dev = engine.device
