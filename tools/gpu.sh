@@ -9,6 +9,7 @@
 #                                           rocprofv3 kernel trace of `bench.py TRACE ARGS`, then one PMC pass per
 #                                           counter group of `bench.py PMC ARGS`, summarised by tools/summarize_prof.py
 #                                           into gpurun_out/prof_NAME/summary.md (copy what is to be kept to profiles/)
+#   tools/gpu.sh stats NAME [bench args]   rocprofv3 --kernel-trace --stats of bench.py (per-kernel durations)
 #   tools/gpu.sh trace NAME [bench args]   kernel trace of bench.py + tools/trace_overlap.py (timeline, overlap)
 #   tools/gpu.sh py <script> [args]         a python tool under a time limit (tools/*.py)
 #
@@ -79,6 +80,16 @@ profile)
   find $OUT -name "*_kernel_trace.csv" -size +2M -delete
   find $OUT -name "*_counter_collection.csv" -size +2M -delete
   cat $OUT/summary.md
+  ;;
+stats)   # NAME [bench args]: rocprofv3 --kernel-trace --stats of bench.py, the per-kernel stats table kept
+  NAME=$1; shift
+  OUT=gpurun_out/stats_$NAME
+  rm -rf $OUT && mkdir -p $OUT
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -- python3 bench.py --no-cpu-baseline "$@" \
+    > $OUT/bench.json 2> $OUT/trace.err || { tail -5 $OUT/trace.err; exit 1; }
+  cp $OUT/t/*/*_kernel_stats.csv $OUT/kernel_stats.csv
+  find $OUT -name "*_kernel_trace.csv" -size +2M -delete
+  head -6 $OUT/kernel_stats.csv | cut -c1-60,150-400; cut -c1-400 $OUT/bench.json
   ;;
 trace)   # NAME [bench args]: kernel trace only, timeline + overlap analysis kept under gpurun_out/trace_NAME/
   NAME=$1; shift
