@@ -748,6 +748,11 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     const int64_t small_row = (int64_t)net_w * 3, small_frame = small_row * net_h;
     const int mode = fused12 ? 0 : h->opt[CD_OPT_RANGE_BY_STAGE];
     const bool one_stream = h->opt[CD_OPT_RANGE_ONE_STREAM] != 0;
+    // fp32 with a resize pass over large frames: the memory-bound resize beside ONE stream of
+    // matrix-bound classification measured faster than beside two (1080p: 402 k against 363 k
+    // frames/s), small frames the other way round (320x180: 424 k against 442 k); the bf16 arithmetics,
+    // whose kernels are short, gain from the second classification stream at every size
+    const bool two_cls = !(two_pass && h->dtype == CD_F32 && (int64_t)H0 * W0 * 3 > (2 << 20));
     hipStream_t pre = one_stream ? s : h->side_pre;
     for (int64_t i = 0; i < nb; ++i) {
         const int64_t a = i * batch;
@@ -755,7 +760,7 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
         const int par = (int)(i & 1), slot = (int)(i % 3);
         // mode 0: the whole batch on one of two alternating streams.  mode 1: block 1 of every batch on the
         // side stream, blocks 2 and 3 on the caller's stream, handed over through the two workspaces.
-        hipStream_t st1 = one_stream ? s : mode == 1 ? h->side_cls : (par ? h->side_cls : s);
+        hipStream_t st1 = one_stream ? s : mode == 1 ? h->side_cls : (par && two_cls ? h->side_cls : s);
         hipStream_t st2 = one_stream || mode == 1 ? s : st1;
         const Workspace& ws = h->ws[par];
         const uint8_t* in = src + a * frame_stride;
