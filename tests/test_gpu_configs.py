@@ -297,3 +297,26 @@ def test_bench_one_gpu_line_has_config4_and_the_separate_roofline_pass():
     assert c4["value"] > 0 and 0 < c4["roofline"]["frac"] < 1
     assert abs(c4["roofline"]["achieved"] - 1_658_892 * c4["value"] / 1e9) < 1.0
     assert set(c4["stages_single_stream_pass"]) >= {"conv1", "conv2", "conv3_head"}
+
+
+def test_bench_under_torch_distributed_run_with_2_ranks():
+    """The driver's other launch form: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`.
+    No launcher directory exists then: rank 0 makes the one the file barrier of the independent-clips leg
+    uses and passes it round through the process group before that group is destroyed."""
+    from cutdet.launch import free_port
+    e = dict(os.environ, CUTDET_BENCH_BACKEND="gloo", CUTDET_BENCH_ONE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CUTDET_RUN_DIR"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--leg-steps", "1", "--leg-warmup", "1"],
+                       env=e, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, _errors(r.stderr)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["n_ranks_seen"] == 2 and out["config"]["frames_per_step"] == 20_000
+    assert out["strong_200k"]["n_ranks_seen"] == 2 and out["strong_200k"]["frames_per_rank"] == 100_000
+    assert "intervals" in out["strong_200k"]["timed_region"]          # 100 000 frames per rank do not fit: chunked
+    assert out["independent_clips"]["n_ranks_seen"] == 2 and out["independent_clips"]["process_group"] == "none"
