@@ -119,8 +119,18 @@ int launch_preprocess(const cd_handle* h, const uint8_t* src, int n, int H0, int
 // - 8 bytes per pixel, {R, G, B, 0} as bfloat16 (a byte value is exact in bfloat16) - into frames with a
 // zero margin: [kCellPad + nh + kCellPad rows][kCellPitch cells], pixel (y, x) at row y + kCellPad, cell
 // x + kCellPad; the margin is zeroed when the buffer is allocated and never written.
+// Workgroups of kResizeThreads threads.  Alone, the kernel is bound by the source bytes a CU has in flight,
+// i.e. by its resident workgroups (each holds one output row's two source rows): with 256 threads the
+// 2048-thread limit of a CU caps them at 8 (1080p, 512 frames: 206 us, 4.1 TB/s), with 128 the LDS caps
+// them at 13 (186 us).  In the range pipeline it runs beside the convolution kernels, and there the 13
+// workgroups' 150 KB of LDS per CU cost more than the faster resize gains (1080p: bf16 1.29 -> 1.22 M
+// frames/s, split bf16 860 -> 851 k): 256 it is.
+#ifndef CD_RESIZE_THREADS
+#define CD_RESIZE_THREADS 256
+#endif
+constexpr int kResizeThreads = CD_RESIZE_THREADS;
 template <bool CELLS>
-__global__ __launch_bounds__(256) void resize_u8_rows_kernel(
+__global__ __launch_bounds__(kResizeThreads) void resize_u8_rows_kernel(
     const uint8_t* __restrict__ src, SampleArgs a, int64_t frame_stride, uint8_t* __restrict__ dst, int nh, int nw,
     int row_bytes_padded, int chan_order) {
     extern __shared__ __attribute__((aligned(16))) uint8_t rows[];   // [2][row_bytes_padded]
@@ -144,11 +154,11 @@ __global__ __launch_bounds__(256) void resize_u8_rows_kernel(
         const uint4* g1 = reinterpret_cast<const uint4*>(frame + (int64_t)r1 * a.row_stride);
         uint4* l0 = reinterpret_cast<uint4*>(rows);
         uint4* l1 = reinterpret_cast<uint4*>(rows + row_bytes_padded);
-        for (int c = tid; c < chunks; c += 256) {
+        for (int c = tid; c < chunks; c += kResizeThreads) {
             l0[c] = g0[c];
             if (two_rows) l1[c] = g1[c];
         }
-        for (int b = (chunks << 4) + tid; b < row_bytes; b += 256) {   // < 16 tail bytes
+        for (int b = (chunks << 4) + tid; b < row_bytes; b += kResizeThreads) {   // < 16 tail bytes
             rows[b] = frame[(int64_t)r0 * a.row_stride + b];
             if (two_rows) rows[row_bytes_padded + b] = frame[(int64_t)r1 * a.row_stride + b];
         }
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void resize_u8_rows_kernel(
     const uint8_t* R0 = rows;
     const uint8_t* R1 = two_rows ? rows + row_bytes_padded : rows;
     uint8_t* out = dst + ((int64_t)f * nh + y) * nw * 3;
-    for (int x = tid; x < nw; x += 256) {
+    for (int x = tid; x < nw; x += kResizeThreads) {
         int v[3];
         if (a.mode == 1) {
             int c0 = a.sx[x] * 3;
@@ -208,8 +218,8 @@ int launch_resize_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int 
     const int padded = (W0 * 3 + 15) & ~15;
     dim3 grid((unsigned)(n * nh)), block(256);
     if (aligned && 2 * padded <= 64 * 1024)
-        hipLaunchKernelGGL(resize_u8_rows_kernel<false>, grid, block, (size_t)2 * padded, s, src, a, frame_stride, dst, nh,
-                           nw, padded, 0);
+        hipLaunchKernelGGL(resize_u8_rows_kernel<false>, grid, dim3(kResizeThreads), (size_t)2 * padded, s, src, a,
+                           frame_stride, dst, nh, nw, padded, 0);
     else
         hipLaunchKernelGGL(resize_u8_generic_kernel, grid, block, 0, s, src, a, frame_stride, dst, nh, nw);
     CD_HIP(hipGetLastError());
@@ -228,7 +238,7 @@ int launch_resize_cells(const cd_handle* h, const uint8_t* src, int n, int H0, i
                         int64_t frame_stride, int chan_order, uint8_t* cells, int nh, int nw, hipStream_t s) {
     SampleArgs a{h->rt_pre.sx, h->rt_pre.ax, h->rt_pre.sy, h->rt_pre.by, h->rt_pre.mode, H0, W0, row_stride, 0, 0, 0, 0, 0};
     const int padded = (W0 * 3 + 15) & ~15;
-    hipLaunchKernelGGL(resize_u8_rows_kernel<true>, dim3((unsigned)(n * nh)), dim3(256), (size_t)2 * padded, s, src, a,
+    hipLaunchKernelGGL(resize_u8_rows_kernel<true>, dim3((unsigned)(n * nh)), dim3(kResizeThreads), (size_t)2 * padded, s, src, a,
                        frame_stride, cells, nh, nw, padded, chan_order);
     CD_HIP(hipGetLastError());
     return CD_OK;
