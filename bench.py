@@ -75,6 +75,10 @@ def compulsory_bytes(h0, w0, net_h):
 PEAK_F32_MFMA_TFLOPS = 157.3                                                # dense fp32 matrix peak, MI355X
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                              # dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
+# measured on an MI355X of this pool (profiles/r01_microbench.txt, profiles/r03_microbench.txt): back-to-back
+# v_mfma_f32_16x16x4_f32 on every SIMD, and a 4 GiB read-only stream (16 bytes per lane)
+MEASURED_F32_MFMA_TFLOPS = 156.0
+MEASURED_HBM_READ_GBS = 6390.0
 
 
 def parse(argv=None):
@@ -394,6 +398,8 @@ def block2_roofline(leg, dtype, height, width, batch, fps_per_gpu):
     return {
         "bound": "mfma", "kernel": "conv2_kernel", "achieved": round(achieved, 2),
         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+        "peak_measured": MEASURED_F32_MFMA_TFLOPS if dtype == "f32" else None,
+        "frac_of_measured_peak": round(achieved / MEASURED_F32_MFMA_TFLOPS, 4) if dtype == "f32" else None,
         "traffic": traffic, "traffic_unit": "bytes per full-batch launch (rocprofv3 PMC, profiles/roofline_traffic.json)",
         "launch_ms": round(conv2_ms, 4), "launches_timed": n_launch, "flops_per_frame": FLOPS_CONV2,
         "frames_per_launch": round(frames_per_launch, 2),
@@ -493,6 +499,7 @@ def main():
                         "run-length encode, host glue/merge, CSV; one step = one pass over the clip",
             "roofline": {"bound": "hbm", "kernel": "whole path (resize + blocks 1-3 per 512-frame batch)",
                          "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "peak_measured": MEASURED_HBM_READ_GBS, "frac_of_measured_peak": round(gbs / MEASURED_HBM_READ_GBS, 4),
                          "algorithmic_bytes_per_frame": bytes_frame,
                          "traffic": traffic_from_profiles(("other_configs", key, "path", "traffic_bytes")),
                          "traffic_unit": "HBM bytes per 512-frame batch over all kernels of the path (rocprofv3 PMC, "
