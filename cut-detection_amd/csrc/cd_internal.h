@@ -82,7 +82,7 @@ struct DeviceParams {
     uint16_t* w2b;  // conv2 / conv3 B fragments in bf16: [27 steps][3 n-tiles][64 lanes][4]
     uint16_t* w3b;
     uint32_t* w1s;  // conv1 B fragments for split bf16: [3 ky][3 n-tiles][64 lanes][hi(R,G,B),0, lo(R,G,B),0] of w / 255
-    uint32_t* w2s;  // conv2 / conv3 B fragments as split bf16: [27 steps][3 n-tiles][hi | lo][64 lanes][w x 4, w x 4]
+    uint32_t* w2s;  // conv2 / conv3 B fragments as split bf16: [27 steps][3 n-tiles][64 lanes][hi x 4, lo x 4]
     uint32_t* w3s;
     float* post;  // [3 layers][3][48]: conv bias, BN scale, BN shift
     float* fc0w;  // [32][768]
@@ -168,6 +168,7 @@ int launch_conv1_u8(const cd_handle* h, const Workspace& ws, const ResizeTables&
                     int W0, int64_t row_stride, int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s);
 int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s);
 int init_conv3_head();
+int init_conv2_split2();     // same, for the two-waves-per-SIMD block-2 kernel of split bf16
 int launch_conv3_head(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, float* logits, float* maxv,
                       int64_t* argmax, hipStream_t s);
 int launch_rle(const cd_handle* h, const int64_t* cls, const float* maxv, int64_t n, int64_t frame_offset,

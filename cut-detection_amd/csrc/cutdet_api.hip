@@ -123,9 +123,11 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
         uint16_t* d = reinterpret_cast<uint16_t*>(&img[dst]);
         for (size_t k = 0; k < (size_t)27 * 3 * 64 * 4; ++k) d[k] = bf16_rne(img[src + k]);
     }
-    // the same fragments as split bf16, hi = bf16(w), lo = bf16(w - hi): per fragment two 1 KB pieces,
-    // lane entries {hi x 4, hi x 4} and {lo x 4, lo x 4} (each half meets one half of the activation cell)
-    const size_t o_w2s = section(27 * 3 * 64 * 8), o_w3s = section(27 * 3 * 64 * 8);
+    // the same fragments as split bf16, hi = bf16(w), lo = bf16(w - hi): 16 bytes per lane, {hi x 4, lo x 4}.
+    // The kernels build the two B operands {hi x 4, hi x 4} and {lo x 4, lo x 4} (each half meets one half of
+    // the activation cell) in registers: stored that way the weights would be twice the bytes, and block 2's
+    // 83 KB already stream from L2 once per wave tile.
+    const size_t o_w2s = section(27 * 3 * 64 * 4), o_w3s = section(27 * 3 * 64 * 4);
     for (int l = 1; l < 3; ++l) {
         const size_t src = l == 1 ? o_w2 : o_w3, dst = l == 1 ? o_w2s : o_w3s;
         uint16_t* d = reinterpret_cast<uint16_t*>(&img[dst]);
@@ -138,9 +140,9 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
                     float hf;
                     std::memcpy(&hf, &hb, 4);
                     const uint16_t lo = bf16_rne(w - hf);
-                    uint16_t* ph = d + (f * 2 * 64 + lane) * 8, *pl = d + ((f * 2 + 1) * 64 + lane) * 8;
-                    ph[e] = ph[4 + e] = hi;
-                    pl[e] = pl[4 + e] = lo;
+                    uint16_t* cell = d + (f * 64 + lane) * 8;
+                    cell[e] = hi;
+                    cell[4 + e] = lo;
                 }
     }
     // block 1 in bf16: fragment (ky, nt), lane (kx = lane>>4, col): W[16nt+col][ci = e][ky][kx], zero for kx = 3 / e = 3
@@ -396,6 +398,15 @@ bool resize_is_point_sample(int H0, int W0, int nh, int nw) {
 
 // Defaults of the per-handle options of cd_forward_u8_range (cd_set_option), from the environment:
 // CUTDET_RANGE_MODE (0 / 1), CUTDET_FUSED12 (0 / 1), CUTDET_RANGE_ONE_STREAM (0 / 1).
+// Timing experiments only (builds with -DCD_EXP_SKIP): CUTDET_SKIP is a mask of the range call's stages to
+// leave out (1 resize pass, 2 block 1, 4 block 2, 8 block 3 + head); the results are then garbage.
+#ifdef CD_EXP_SKIP
+static int skip_mask() { static const int m = [] { const char* e = std::getenv("CUTDET_SKIP"); return e ? std::atoi(e) : 0; }(); return m; }
+#define CD_SKIP_IF(bit) if (!(skip_mask() & (bit)))
+#else
+#define CD_SKIP_IF(bit)
+#endif
+
 int env_option(const char* name, int fallback) {
     const char* e = std::getenv(name);
     return e && (e[0] == '0' || e[0] == '1') && !e[1] ? e[0] - '0' : fallback;
@@ -476,6 +487,8 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->opt[CD_OPT_RANGE_BY_STAGE] = env_option("CUTDET_RANGE_MODE", 0);
     h->opt[CD_OPT_FUSE_BLOCKS12] = env_option("CUTDET_FUSED12", 0);
     h->opt[CD_OPT_RANGE_ONE_STREAM] = env_option("CUTDET_RANGE_ONE_STREAM", 0);
+    h->opt[CD_OPT_SPLIT_TWO_WAVES] = env_option("CUTDET_S2_TWO_WAVES", 0);
+    h->opt[CD_OPT_RESIZE_ROWS] = env_option("CUTDET_RESIZE_ROWS", 0);
     ParamOffsets off;
     std::vector<float> img = pack_params(f.data(), &off);
     auto fail = [&](int code) { cd_destroy(h); return code; };
@@ -507,7 +520,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     CD_TRY(hipMalloc(reinterpret_cast<void**>(&h->tickets), 2048 * sizeof(unsigned)));
     CD_TRY(hipMemset(h->tickets, 0, 2048 * sizeof(unsigned)));
 #undef CD_TRY
-    if (init_conv3_head() != CD_OK) return fail(CD_EHIP);
+    if (init_conv3_head() != CD_OK || init_conv2_split2() != CD_OK) return fail(CD_EHIP);
     if (init_static_scratch(device) != CD_OK) return fail(CD_EHIP);
     *out = h;
     return CD_OK;
@@ -789,7 +802,7 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
         if (two_pass) {
             uint8_t* dst = h->small + (size_t)slot * h->small_bytes;
             if (i >= 3) CD_HIP(hipStreamWaitEvent(pre, h->ev_free[slot], 0));   // batch i-3 is done with the slot
-            {
+            CD_SKIP_IF(1) {
                 StageTimer t(h, CD_STAGE_PREPROCESS, pre);
                 if ((rc = launch_resize_u8(h, in, k, H0, W0, row_stride, frame_stride, dst, net_h, net_w, pre))) return rc;
             }
@@ -798,7 +811,7 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
             in = dst; fH = net_h; fW = net_w; frs = small_row; ffs = small_frame;
         }
         if (mode == 1 && i >= 2) CD_HIP(hipStreamWaitEvent(st1, h->ev_a1free[par], 0));   // block 2 of batch i-2 has read act1
-        {
+        CD_SKIP_IF(2) {
             StageTimer t(h, CD_STAGE_CONV1, st1);
             if ((rc = launch_conv1_u8(h, ws, *rt, in, k, fH, fW, frs, ffs, chan_order, g, st1))) return rc;
         }
@@ -807,9 +820,10 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
             CD_HIP(hipEventRecord(h->ev_a1ready[par], st1));
             CD_HIP(hipStreamWaitEvent(st2, h->ev_a1ready[par], 0));
         }
-        { StageTimer t(h, CD_STAGE_CONV2, st2); if ((rc = launch_conv2(h, ws, k, g, st2))) return rc; }
+        CD_SKIP_IF(4) { StageTimer t(h, CD_STAGE_CONV2, st2); if ((rc = launch_conv2(h, ws, k, g, st2))) return rc; }
         if (mode == 1) CD_HIP(hipEventRecord(h->ev_a1free[par], st2));
         StageTimer t(h, CD_STAGE_CONV3_HEAD, st2);
+        CD_SKIP_IF(8)
         if ((rc = launch_conv3_head(h, ws, k, g, logits + a * kOut, maxv ? maxv + a : nullptr,
                                     argmax ? argmax + a : nullptr, st2))) return rc;
     }

@@ -43,14 +43,14 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 // is stored as two bfloat16, hi = bf16(v) and lo = bf16(v - hi), and the 16-byte cell that holds
 // four fp32 channels in fp32 mode holds {hi x 4, lo x 4} of the same four channels.  That cell is,
 // as it stands, a lane's A operand of v_mfma_f32_16x16x32_bf16 (8 K slots per lane: which channel
-// sits in which slot is free as long as A and B agree).  With the weights packed as {w_hi x 4,
+// sits in which slot is free as long as A and B agree).  With B operands {w_hi x 4,
 // w_hi x 4} and {w_lo x 4, w_lo x 4}, two such MFMAs give
 //     (a_hi + a_lo) * w_hi + (a_hi + a_lo) * w_lo,
 // the complete product of the split values, in 2 x 16 cycles where fp32 needs 4 x 32.  What is lost
 // is only the splitting itself: |v - (hi + lo)| <= 2^-17 |v|.
 constexpr int kF32 = 0, kBF16 = 1, kS2 = 2;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct SplitB { u32x4 h, l; };       // B fragments of one (step, n-tile): {w_hi, w_hi} and {w_lo, w_lo}
+struct SplitB { u32x4 v; };          // weights of one (step, n-tile) as loaded: {w_hi x 4, w_lo x 4} per lane
 template <int P> struct Prec;
 template <> struct Prec<kF32> {
     typedef float elem; typedef f32x4 frag; typedef f32x4 bfrag;
@@ -72,12 +72,12 @@ template <> struct Prec<kS2> {
     typedef uint32_t elem; typedef u32x4 frag; typedef SplitB bfrag;   // element = one channel's (hi, lo), by size only
     static constexpr int kSub = 2;
     static constexpr int kEs = 4;
-    static constexpr int kWBytes = 32;
+    static constexpr int kWBytes = 16;
 #ifndef CD_S2_BDIST
 #define CD_S2_BDIST 2
 #endif
     static constexpr int kBDist = CD_S2_BDIST;   // a step is only ~860 cycles here: one step ahead does not cover an L2 round trip
-    static constexpr int kBLoads = 6;
+    static constexpr int kBLoads = 3;
 };
 
 // Weight fragments are read through a buffer descriptor: the address is one per-lane VGPR
@@ -92,10 +92,13 @@ template <int P>
 __device__ __forceinline__ typename Prec<P>::bfrag load_frag(__amdgpu_buffer_rsrc_t r, int lane, int idx) {
     if constexpr (P == kBF16)
         return __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8, idx * 512, 0));
-    else if constexpr (P == kS2)      // [idx][hi | lo][lane][16 bytes]
-        return SplitB{__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 2048, 0)),
-                      __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 2048 + 1024, 0))};
-    else
+    else if constexpr (P == kS2) {    // [idx][lane]{hi x 4, lo x 4}: one load; mfma_frag builds the operands {hi, hi} / {lo, lo}
+#ifdef CD_EXP_WHOT
+        idx &= 1;                     // timing experiment: every weight load hits L1 (wrong results)
+#endif
+        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
+        return SplitB{v};
+    } else
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
 }
 
@@ -110,7 +113,9 @@ __device__ __forceinline__ f32x4 mfma_frag(const typename Prec<P>::frag& a, cons
     if constexpr (P == kBF16) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
     else if constexpr (P == kS2)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                       __builtin_bit_cast(bf16x8, e == 0 ? b.l : b.h), c, 0, 0, 0);
+                                                       __builtin_bit_cast(bf16x8, e == 0 ? u32x4{b.v[2], b.v[3], b.v[2], b.v[3]}
+                                                                                         : u32x4{b.v[0], b.v[1], b.v[0], b.v[1]}),
+                                                       c, 0, 0, 0);
     else return mfma4(a[e], b[e], c);
 }
 // two fp32 values -> two bf16 (round to nearest even) in one dword, `lo` in the low half
@@ -180,6 +185,9 @@ __device__ __forceinline__ void xcd_frame_tile(int b, int per_frame, int& frame,
 // 4-byte load at any byte address (the hardware handles unaligned global loads)
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
+#ifndef CD_DMA_AUX
+#define CD_DMA_AUX 0     // cache-policy bits of block 2's patch copies (global_load ... lds)
+#endif
 #ifndef CD_DIAG_P
 #define CD_DIAG_P 0      // diagnostic builds: the arithmetic (0 fp32, 1 bf16, 2 split bf16) whose blocks 2 / 3 write time stamps
 #endif
@@ -1027,7 +1035,7 @@ __device__ __forceinline__ void conv2_dma_group(const char* src, typename Prec<B
 #pragma unroll
     for (int it = 0; it < G2<BF>::kDma; ++it)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint32_t)rel[it]),
-                                         (__attribute__((address_space(3))) void*)(d + it * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(d + it * 1024), 16, 0, CD_DMA_AUX);
 }
 
 // One (tile, channel group) unit: 9 pipelined steps.  G, the channel group, is a compile-time
@@ -1106,7 +1114,7 @@ __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, 
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(next_src + (uint32_t)rel[it]),
                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(const_cast<elem*>(bufs) + other_off) + it * 1024),
-                        16, 0, 0);
+                        16, 0, CD_DMA_AUX);
 #endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1184,7 +1192,7 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     auto valid = [&](int id) {
         int frame, tt;
         xcd_frame_tile(id, per_frame, frame, tt);
-        return id < total_tiles && frame < n;
+        return id >= 0 && id < total_tiles && frame < n;
     };
     // tile id -> source patch origin / destination frame; invalid ids map to tile 0 so that the
     // last look-ahead copy of a wave stays in bounds (its data is never used)
@@ -1265,7 +1273,7 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
         for (int s0 = 0; s0 < kBD; ++s0)
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
-                if constexpr (BF == kS2) { asm volatile("" : "+v"(b[s0][nt].h)); asm volatile("" : "+v"(b[s0][nt].l)); }
+                if constexpr (BF == kS2) asm volatile("" : "+v"(b[s0][nt].v));
                 else asm volatile("" : "+v"(b[s0][nt]));
             }
 #ifdef CD_DIAG
@@ -1309,6 +1317,8 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+int launch_conv2_split2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s);
+
 int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s) {
     const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
     const int total = (int)xcd_grid(n, tiles_x * tiles_y);
@@ -1321,6 +1331,8 @@ int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry&
         hipLaunchKernelGGL(conv2_kernel<kBF16>, dim3((unsigned)grid), dim3(64), 0, s,
                            reinterpret_cast<const uint16_t*>(ws.act1), reinterpret_cast<uint16_t*>(ws.act2),
                            (const void*)h->p.w2b, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
+    else if (h->dtype == CD_BF16_SPLIT && h->opt[CD_OPT_SPLIT_TWO_WAVES])
+        return launch_conv2_split2(h, ws, n, g, s);
     else if (h->dtype == CD_BF16_SPLIT)
         hipLaunchKernelGGL(conv2_kernel<kS2>, dim3((unsigned)grid), dim3(64), 0, s,
                            reinterpret_cast<const uint32_t*>(ws.act1), reinterpret_cast<uint32_t*>(ws.act2),
@@ -1484,6 +1496,16 @@ __device__ __forceinline__ void conv12_copy_cells(const char* src, char* cin_lds
 // buffer descriptor) are requested one per MFMA during the current step; the A operands of a unit's
 // first step are read at its start (the patch did not exist earlier), its weights were requested
 // during the previous unit's last step.
+// Byte offset, from a patch's first activation, of the 16 bytes lane `lane` copies in copy instruction
+// `it` of a 14x14 split-bf16 patch (4 pieces per pixel; same values as conv2_kernel's rel[] table, worked
+// out from two compares instead of held in 13 registers).  rel_lane = (lane / 4) * 192 + (lane % 4) * 16.
+__device__ __forceinline__ int conv2_rel(int it, int lane, int rel_lane) {
+    const int start = 16 * it, row0 = start / kP2, col0 = start % kP2;    // constants once unrolled
+    const int q = lane >> 2;
+    const int wraps = (q >= kP2 - col0 ? 1 : 0) + (q >= 2 * kP2 - col0 ? 1 : 0);
+    return (row0 * kP1W + col0) * kC * 4 + rel_lane + wraps * ((kP1W - kP2) * kC * 4);
+}
+
 template <int G>
 __device__ __forceinline__ void conv12_consume(const uint32_t* pb, const int (&base)[3], __amdgpu_buffer_rsrc_t wr,
                                                int lane, u32x4 (&a)[2][3][3], SplitB (&b)[2][3], f32x4 (&acc)[3][3][3]) {
@@ -1559,7 +1581,7 @@ __global__ __launch_bounds__(128, 2) void conv12_split_kernel(const uint8_t* __r
     auto valid = [&](int id) {
         int frame, tt;
         xcd_frame_tile(id, per_frame, frame, tt);
-        return id < total_tiles && frame < n;
+        return id >= 0 && id < total_tiles && frame < n;
     };
     struct Tile { const char* src; uint32_t* dst; int ty, tx; };
     auto locate = [&](int id) {
@@ -1726,6 +1748,216 @@ __global__ __launch_bounds__(128, 2) void conv12_split_kernel(const uint8_t* __r
         id = next_id;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// Block 2 in split bf16 with TWO waves per SIMD.
+// With 16-cycle MFMAs the issue cost of a step's memory instructions no longer hides in the MFMA gaps:
+// alone on its SIMD, conv2_kernel<kS2>'s wave keeps the matrix pipe ~65 % busy.  Here a second wave
+// fills the gaps.  To fit two, a wave has 256 registers and ONE patch buffer:
+//   - a step's MFMAs run patch row by patch row (t outermost), so only the first row's operands have to
+//     be there when the step starts: they are read during the previous step (12 registers), the other
+//     two rows at the start of the step itself, behind its first MFMAs (no second 36-register set);
+//   - the weights (16 bytes per lane and fragment, {hi x 4, lo x 4}) are requested kS2Ahead steps
+//     ahead: they come from L2 (a CU's L1 does not hold the 83 KB a tile cycles through), behind the
+//     other waves' patch copies, and one step of a wave that shares its SIMD is not always enough;
+//   - the next unit's patch is copied over the current one during the unit's last step, once that
+//     step's own operands have been read; what is left of the copy's latency is the other wave's time
+//     on the pipe.
+// Every accumulator sees its products in the order conv2_kernel<kS2> adds them: same bits.
+// ------------------------------------------------------------------------------------------
+#ifndef CD_S2W2_AHEAD
+#define CD_S2W2_AHEAD 2
+#endif
+constexpr int kS2Ahead = CD_S2W2_AHEAD, kS2Sets = kS2Ahead + 1;
+constexpr int kS2W2WaveLds = 16384;      // per wave: one patch buffer (13 312 bytes) + the epilogue's 16 x 48 floats
+static_assert(27 % kS2Sets == 0, "the weight register sets must come round at a tile boundary");
+
+template <int G, int WAVES>
+__device__ __forceinline__ void conv2_split2_unit(uint32_t* pb, const int (&base)[3], __amdgpu_buffer_rsrc_t wr, int lane,
+                                                  u32x4 (&a)[3][3], u32x4 (&an)[3], SplitB (&b)[kS2Sets][3],
+                                                  f32x4 (&acc)[3][3][3], const char* next_src, int rel_lane) {
+    constexpr int kDma = G2<kS2>::kDma;
+    // the waves of a workgroup start a unit together: they then ask for the same weight lines within a few
+    // hundred cycles of each other, and all but the first request are served by the CU's L1
+    if (WAVES > 1) __builtin_amdgcn_s_barrier();
+    // the patch (copied during the previous unit's last step, or by the prologue) must have landed; the
+    // three weight loads issued after the copy may still be in flight (VMEM completes in issue order)
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[0][j] = *reinterpret_cast<const u32x4*>(pb + base[j]);
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+        constexpr int kFirst = G * 9;
+        const int s = kFirst + kk, cb = s % kS2Sets, lb = (s + kS2Ahead) % kS2Sets;
+        const int sw = (s + kS2Ahead) % 27, wk = sw % 9, wg = sw / 9;          // the step whose weights are requested now
+        const int off = (kk / 3) * kP2 * 16 + (kk % 3) * 16;
+        const int noff = ((kk + 1) / 3) * kP2 * 16 + ((kk + 1) % 3) * 16;
+#pragma unroll
+        for (int m = 0; m < 54; ++m) {
+            const int t = m / 18, e = (m / 9) % 2, j = (m / 3) % 3, nt = m % 3;
+            if (G == 0 && kk == 0 && e == 0)
+                acc[t][j][nt] = mfma_frag<kS2>(a[t][j], b[cb][nt], e, f32x4{0.f, 0.f, 0.f, 0.f});
+            else
+                acc[t][j][nt] = mfma_frag<kS2>(a[t][j], b[cb][nt], e, acc[t][j][nt]);
+            const int n_side = kk < 8 ? 12 : 9 + kDma;
+            if (m < n_side) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < 6) {                        // this step's rows 1 and 2
+                    const int lt = 1 + m / 3, lj = m % 3;
+                    a[lt][lj] = *reinterpret_cast<const u32x4*>(pb + base[lj] + off + lt * kP2 * 16);
+                } else if (kk < 8) {
+                    if (m < 9) b[lb][m - 6] = load_frag<kS2>(wr, lane, (wk * 3 + wg) * 3 + (m - 6));
+                    else an[m - 9] = *reinterpret_cast<const u32x4*>(pb + base[m - 9] + noff);      // next step's row 0
+                } else {
+                    // last step: nothing reads the patch after the six reads above
+                    if (m == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (m < 6 + kDma) {
+                        const int it = m - 6;
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(next_src + (uint32_t)conv2_rel(it, lane, rel_lane)),
+                            (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(pb) + it * 1024), 16, 0, CD_DMA_AUX);
+                    } else {
+                        b[lb][m - 6 - kDma] = load_frag<kS2>(wr, lane, (wk * 3 + wg) * 3 + (m - 6 - kDma));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (kk < 8) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[0][j] = an[j];
+        }
+    }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 1 ? 2 : 1) void conv2_split2_kernel(
+    const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const void* __restrict__ wfrag,
+    const float* __restrict__ post, int n, int Hin, int Hp, int tiles_x, int tiles_y, int total_tiles) {
+    constexpr int kDma = G2<kS2>::kDma, kBuf = G2<kS2>::kBufElems;
+    static_assert((kBuf + 16 * kC) * 4 == kS2W2WaveLds, "LDS per wave");
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_w2[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* patch = dyn_w2 + wave * (kS2W2WaveLds / 4);
+    float* scratch = reinterpret_cast<float*>(patch + kBuf);             // the epilogue's transpose
+    const int slot = (int)blockIdx.x * WAVES + wave, stride = (int)gridDim.x * WAVES;
+    const int per_frame = tiles_x * tiles_y;
+    const int64_t in_frame = (int64_t)(Hin + 2) * kP1W * kC * 4, out_frame = (int64_t)(Hp + 2) * kP2W * kC;
+    auto valid = [&](int id) {
+        int frame, tt;
+        xcd_frame_tile(id, per_frame, frame, tt);
+        return id >= 0 && id < total_tiles && frame < n;
+    };
+    // invalid ids map to tile 0 of frame 0: the copy a wave's last unit issues stays in bounds and is never used
+    auto locate = [&](int id) {
+        int frame = 0, tt = 0;
+        if (valid(id)) xcd_frame_tile(id, per_frame, frame, tt);
+        Conv2Tile<kS2> t;
+        t.ty = tt / tiles_x; t.tx = tt % tiles_x;
+        t.src = reinterpret_cast<const char*>(in) + frame * in_frame + ((int64_t)(12 * t.ty) * kP1W + 12 * t.tx) * kC * 4;
+#ifdef CD_EXP_DMAHOT
+        t.src = reinterpret_cast<const char*>(in);       // timing experiment: every patch copy hits the caches (wrong results)
+#endif
+        t.dst = out + frame * out_frame;
+        return t;
+    };
+    int id = slot;
+    // every wave of a workgroup meets the others at three barriers per round, tiles or not
+    int rounds_left = WAVES > 1 ? (total_tiles + stride - 1) / stride : 0;
+    if (!valid(id)) {
+        for (; rounds_left > 0; --rounds_left)
+            for (int g = 0; g < 3; ++g) __builtin_amdgcn_s_barrier();
+        return;
+    }
+    const int rel_lane = (lane >> 2) * kC * 4 + (lane & 3) * 16;
+    const int i = lane & 15, kq = lane >> 4;
+    int base[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) base[j] = ((3 * (i >> 2)) * kP2 + 4 * j + (i & 3)) * 16 + 4 * kq;
+    const __amdgpu_buffer_rsrc_t wr = weight_rsrc<kS2>(wfrag);
+    Conv2Tile<kS2> cur = locate(id);
+    int next_id = valid(id + stride) ? id + stride : -1;
+    Conv2Tile<kS2> nxt = locate(next_id);
+    u32x4 a[3][3], an[3];
+    SplitB b[kS2Sets][3];
+    f32x4 acc[3][3][3];
+#pragma unroll
+    for (int it = 0; it < kDma; ++it)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(cur.src + (uint32_t)conv2_rel(it, lane, rel_lane)),
+            (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(patch) + it * 1024), 16, 0, CD_DMA_AUX);
+    // the weights of the first kS2Ahead steps (step s of a tile = kernel tap s % 9 of channel group s / 9)
+#pragma unroll
+    for (int s0 = 0; s0 < kS2Ahead; ++s0)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) b[s0][nt] = load_frag<kS2>(wr, lane, ((s0 % 9) * 3 + s0 / 9) * 3 + nt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int kGroupBytes = 64;
+    for (;;) {
+        conv2_split2_unit<0, WAVES>(patch, base, wr, lane, a, an, b, acc, cur.src + kGroupBytes, rel_lane);
+        conv2_split2_unit<1, WAVES>(patch, base, wr, lane, a, an, b, acc, cur.src + 2 * kGroupBytes, rel_lane);
+        conv2_split2_unit<2, WAVES>(patch, base, wr, lane, a, an, b, acc, nxt.src, rel_lane);
+        --rounds_left;
+        {
+            // bias / BatchNorm constants are fetched here (L1 hits) rather than held in registers all tile long
+            const int q = lane >> 4, ch = lane & 15;
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const int c = nt * 16 + ch;
+                const float bias = post[c], scale = post[kC + c], shift = post[2 * kC + c];
+                const float m[4] = {window_max<0>(acc, nt), window_max<1>(acc, nt), window_max<2>(acc, nt),
+                                    window_max<3>(acc, nt)};
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi)
+                    scratch[(4 * q + wi) * kC + c] = fmaf(fmaxf(m[wi] + bias, 0.f), scale, shift);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int f = it * 64 + lane;                 // 16-byte piece f of 16 windows x 192 bytes
+                const int win = f / 12, c4 = f % 12;
+                const int py = cur.ty * 4 + (win >> 2), px = cur.tx * 4 + (win & 3);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + win * kC + 4 * c4);
+                if (py < Hp && px < kW2)
+                    *reinterpret_cast<u32x4*>(cur.dst + ((int64_t)(py + 1) * kP2W + px + 1) * kC + 4 * c4) = split_bf16(v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (next_id < 0) break;
+        id = next_id;
+        cur = nxt;
+        next_id = valid(id + stride) ? id + stride : -1;
+        nxt = locate(next_id);
+    }
+    // the copy and the weight loads of a unit that will never run are still in flight
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (; rounds_left > 0; --rounds_left)
+        for (int g = 0; g < 3; ++g) __builtin_amdgcn_s_barrier();
+}
+
+#ifndef CD_S2W2_WAVES
+#define CD_S2W2_WAVES 1
+#endif
+int init_conv2_split2() {
+    CD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_split2_kernel<CD_S2W2_WAVES>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, CD_S2W2_WAVES * kS2W2WaveLds));
+    return CD_OK;
+}
+
+int launch_conv2_split2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s) {
+    constexpr int kWaves = CD_S2W2_WAVES;
+    const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
+    const int total = (int)xcd_grid(n, tiles_x * tiles_y);
+    const int want = (total + kWaves - 1) / kWaves, grid = want < 2048 / kWaves ? want : 2048 / kWaves;
+    hipLaunchKernelGGL(conv2_split2_kernel<kWaves>, dim3((unsigned)grid), dim3(64 * kWaves), kWaves * kS2W2WaveLds, s,
+                       reinterpret_cast<const uint32_t*>(ws.act1), reinterpret_cast<uint32_t*>(ws.act2),
+                       (const void*)h->p.w2s, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
+    CD_HIP(hipGetLastError());
+    return CD_OK;
 }
 
 int launch_conv12_split(const cd_handle* h, const Workspace& ws, const uint8_t* cells, int n, const Geometry& g,

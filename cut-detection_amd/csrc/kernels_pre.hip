@@ -200,6 +200,133 @@ __global__ __launch_bounds__(kResizeThreads) void resize_u8_rows_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same resize without LDS: one thread per output pixel, its taps read straight from global memory
+// as unaligned dwords (the six bytes of two neighbouring source pixels sit in eight), kDirectRows output
+// rows per thread so that a wave has 4 x kDirectRows loads in flight.  Neighbouring lanes' taps are a few
+// bytes apart, so a wave-wide load touches about as many cache lines as a row copy would, and every
+// source line is still fetched once.  Why it exists: the row-staging kernel above holds 11.5 KB of LDS
+// per workgroup, and in the range pipeline the convolution kernels leave a CU no LDS to give - its
+// workgroups then wait for them instead of running beside them.  This one needs registers only.
+// The three output bytes of four neighbouring pixels leave as three dwords (lane exchange, no LDS memory).
+// ------------------------------------------------------------------------------------------
+constexpr int kDirectRows = 4;
+
+// the 8 bytes at row + off (any alignment), shifted so that byte 0 is row[off]; reads stay inside the row:
+// near its end the window slides back and the value is shifted down instead (row_bytes >= 8)
+__device__ __forceinline__ uint64_t load8_in_row(const uint8_t* row, int off, int row_bytes) {
+    typedef uint32_t __attribute__((aligned(1))) u32_any;
+    const int at = min(off, row_bytes - 8);
+    const uint32_t lo = *reinterpret_cast<const u32_any*>(row + at), hi = *reinterpret_cast<const u32_any*>(row + at + 4);
+    return ((uint64_t)hi << 32 | lo) >> (8 * (off - at));
+}
+
+// Grid: x = 64-pixel column blocks, y = blocks of 4 row groups (one per wave), z = frame.
+template <int MODE, bool CELLS>
+__global__ __launch_bounds__(256) void resize_u8_direct_kernel(
+    const uint8_t* __restrict__ src, SampleArgs a, int64_t frame_stride, uint8_t* __restrict__ dst, int nh, int nw,
+    int chan_order) {
+    const int x = min((int)(blockIdx.x * 64 + threadIdx.x), nw - 1);        // surplus lanes repeat the last pixel, unstored
+    const bool x_live = (int)(blockIdx.x * 64 + threadIdx.x) < nw;
+    // (a wave is one row group: everything that depends on the row only is made scalar work)
+    const int y0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + threadIdx.y) * kDirectRows);
+    const int f = blockIdx.z;
+    if (y0 >= nh) return;                                                   // whole waves: a wave is one row group
+    const uint8_t* frame = src + (int64_t)f * frame_stride;
+    const int row_bytes = a.W0 * 3;
+    int off;
+    uint32_t coef = 0;                           // bilinear: the horizontal coefficient pair, a0 | a1 << 16
+    // byte selectors that put source bytes cc and cc + 3 (the pixel and its right neighbour) into the two
+    // halves of a dword; at the right edge the neighbour is the pixel itself
+    uint32_t sel[3] = {0x0c030c00u, 0x0c040c01u, 0x0c050c02u};
+    if (MODE == 1) off = a.sx[x] * 3;
+    else if (MODE == 2) off = 6 * x;
+    else {
+        const int c0 = a.sx[x];
+        off = c0 * 3;
+        coef = *reinterpret_cast<const uint32_t*>(a.ax + 2 * x);
+        if (c0 + 1 > a.W0 - 1) { sel[0] = 0x0c000c00u; sel[1] = 0x0c010c01u; sel[2] = 0x0c020c02u; }
+    }
+    uint64_t t0[kDirectRows], t1[kDirectRows];
+    int b0[kDirectRows], b1[kDirectRows];
+#pragma unroll
+    for (int r = 0; r < kDirectRows; ++r) {
+        const int y = min(y0 + r, nh - 1);       // rows past the end repeat the last one and are not stored
+        int r0, r1;
+        if (MODE == 2) { r0 = 2 * y; r1 = 2 * y + 1; b0[r] = b1[r] = 0; }
+        else {
+            const int sy = a.sy[y];
+            r0 = min(max(sy, 0), a.H0 - 1);
+            r1 = min(max(sy + 1, 0), a.H0 - 1);
+            b0[r] = MODE == 0 ? a.by[2 * y] : 0;
+            b1[r] = MODE == 0 ? a.by[2 * y + 1] : 0;
+        }
+        t0[r] = load8_in_row(frame + (int64_t)r0 * a.row_stride, off, row_bytes);
+        // (a zero vertical weight makes the second row's value irrelevant; reading it anyway keeps the loads
+        // unconditional, and r1 is a valid row)
+        t1[r] = MODE == 1 ? t0[r] : load8_in_row(frame + (int64_t)r1 * a.row_stride, off, row_bytes);
+    }
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 0; r < kDirectRows; ++r) {
+        const int y = y0 + r;
+        int v[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            if (MODE == 1) v[cc] = (int)(t0[r] >> (8 * cc)) & 255;
+            else {
+                const uint32_t q0 = __builtin_amdgcn_perm((uint32_t)(t0[r] >> 32), (uint32_t)t0[r], sel[cc]);
+                const uint32_t q1 = __builtin_amdgcn_perm((uint32_t)(t1[r] >> 32), (uint32_t)t1[r], sel[cc]);
+                if (MODE == 2) {
+                    const uint32_t sum = q0 + q1;                          // two 16-bit lanes, no carry between them
+                    v[cc] = (int)((sum & 0xFFFFu) + (sum >> 16) + 2) >> 2;
+                } else {
+                    const int S0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, q0), __builtin_bit_cast(u16x2, coef), 0u, false);
+                    const int S1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, q1), __builtin_bit_cast(u16x2, coef), 0u, false);
+                    // (24-bit multiplies: |b| <= 2^11 and S >> 4 < 2^15 - the full 32-bit multiply runs at a quarter of the rate)
+                    const int t = ((__mul24(b0[r], S0 >> 4) >> 16) + (__mul24(b1[r], S1 >> 4) >> 16) + 2) >> 2;
+                    v[cc] = min(max(t, 0), 255);
+                }
+            }
+        }
+        if constexpr (CELLS) {
+            const bool bgr = chan_order == CD_BGR;
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t rg2 = {(__bf16)(float)v[bgr ? 2 : 0], (__bf16)(float)v[1]};
+            const bf16x2_t b2 = {(__bf16)(float)v[bgr ? 0 : 2], (__bf16)0.f};
+            uint2* cells = reinterpret_cast<uint2*>(dst) +
+                           ((int64_t)f * (nh + 2 * kCellPad) + y + kCellPad) * kCellPitch + kCellPad;
+            if (x_live && y < nh) cells[x] = uint2{__builtin_bit_cast(uint32_t, rg2), __builtin_bit_cast(uint32_t, b2)};
+        } else {
+            // pixels 4q .. 4q+3 of a row are lanes 4q .. 4q+3 of the wave (nw is a multiple of 4): lanes 0, 1, 2
+            // of the quad store dwords 0, 1, 2 of its 12 bytes
+            const uint32_t own = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16;
+            const uint32_t nxt = (uint32_t)__shfl_down((int)own, 1, 64);
+            const int q = threadIdx.x & 3;
+            const uint32_t d = q == 0 ? own | nxt << 24 : q == 1 ? own >> 8 | nxt << 16 : own >> 16 | nxt << 8;
+            uint32_t* out = reinterpret_cast<uint32_t*>(dst + ((int64_t)f * nh + y) * nw * 3) + (x >> 2) * 3 + q;
+            if (x_live && y < nh && q < 3) *out = d;
+        }
+    }
+}
+
+// launches the direct kernel for the table's mode; false when it does not apply (then the callers fall back)
+template <bool CELLS>
+static bool launch_resize_direct(const SampleArgs& a, const uint8_t* src, int64_t frame_stride, uint8_t* dst, int n,
+                                 int nh, int nw, int chan_order, hipStream_t s) {
+    if (nw % 4 != 0 || a.W0 * 3 < 8 || (reinterpret_cast<uintptr_t>(dst) & 3) != 0 || n > 65535) return false;
+    if (a.mode == 0 && (reinterpret_cast<uintptr_t>(a.ax) & 3) != 0) return false;
+    const int row_groups = (nh + kDirectRows - 1) / kDirectRows;
+    const dim3 grid((unsigned)((nw + 63) / 64), (unsigned)((row_groups + 3) / 4), (unsigned)n), block(64, 4);
+    if (a.mode == 0)
+        hipLaunchKernelGGL((resize_u8_direct_kernel<0, CELLS>), grid, block, 0, s, src, a, frame_stride, dst, nh, nw, chan_order);
+    else if (a.mode == 1)
+        hipLaunchKernelGGL((resize_u8_direct_kernel<1, CELLS>), grid, block, 0, s, src, a, frame_stride, dst, nh, nw, chan_order);
+    else
+        hipLaunchKernelGGL((resize_u8_direct_kernel<2, CELLS>), grid, block, 0, s, src, a, frame_stride, dst, nh, nw, chan_order);
+    return true;
+}
+
 // rows that are not 16-byte aligned: taps straight from global memory
 __global__ __launch_bounds__(256) void resize_u8_generic_kernel(
     const uint8_t* __restrict__ src, SampleArgs a, int64_t frame_stride, uint8_t* __restrict__ dst, int nh, int nw) {
@@ -217,7 +344,8 @@ int launch_resize_u8(const cd_handle* h, const uint8_t* src, int n, int H0, int 
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     const int padded = (W0 * 3 + 15) & ~15;
     dim3 grid((unsigned)(n * nh)), block(256);
-    if (aligned && 2 * padded <= 64 * 1024)
+    if (!h->opt[CD_OPT_RESIZE_ROWS] && launch_resize_direct<false>(a, src, frame_stride, dst, n, nh, nw, 0, s)) {
+    } else if (aligned && 2 * padded <= 64 * 1024)
         hipLaunchKernelGGL(resize_u8_rows_kernel<false>, grid, dim3(kResizeThreads), (size_t)2 * padded, s, src, a,
                            frame_stride, dst, nh, nw, padded, 0);
     else
@@ -238,6 +366,8 @@ int launch_resize_cells(const cd_handle* h, const uint8_t* src, int n, int H0, i
                         int64_t frame_stride, int chan_order, uint8_t* cells, int nh, int nw, hipStream_t s) {
     SampleArgs a{h->rt_pre.sx, h->rt_pre.ax, h->rt_pre.sy, h->rt_pre.by, h->rt_pre.mode, H0, W0, row_stride, 0, 0, 0, 0, 0};
     const int padded = (W0 * 3 + 15) & ~15;
+    if (!h->opt[CD_OPT_RESIZE_ROWS] && launch_resize_direct<true>(a, src, frame_stride, cells, n, nh, nw, chan_order, s)) {
+    } else
     hipLaunchKernelGGL(resize_u8_rows_kernel<true>, dim3((unsigned)(n * nh)), dim3(kResizeThreads), (size_t)2 * padded, s, src, a,
                        frame_stride, cells, nh, nw, padded, chan_order);
     CD_HIP(hipGetLastError());

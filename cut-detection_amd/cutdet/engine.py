@@ -85,8 +85,9 @@ class Engine:
         return n, H0, W0, frames.stride(1), frames.stride(0) if n > 1 else max(frames.stride(0), frames.stride(1) * H0)
 
     def set_option(self, name, value):
-        """Scheduling options of forward_u8_range (cd_set_option): "range_by_stage", "fuse_blocks12",
-        "range_one_stream"; value 0 or 1.  Every setting gives the same bits."""
+        """cd_set_option: how forward_u8_range schedules its work ("range_by_stage", "fuse_blocks12",
+        "range_one_stream") and which of two kernels runs ("split_two_waves": block 2 of bf16_split;
+        "resize_rows": the stand-alone resize); value 0 or 1.  Every setting gives the same bits."""
         check(lib.cd_set_option(self._h, _lib.OPTIONS[name], int(bool(value))))
 
     def reserve(self, max_frames, net_h=144):

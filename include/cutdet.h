@@ -167,7 +167,9 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
 
 /* How cd_forward_u8_range schedules its work; every setting gives the same bits.  No counterpart in the
  * reference.  The defaults can also be set through the environment when a handle is created
- * (CUTDET_RANGE_MODE, CUTDET_FUSED12, CUTDET_RANGE_ONE_STREAM = 0 or 1).
+ * (CUTDET_RANGE_MODE, CUTDET_FUSED12, CUTDET_RANGE_ONE_STREAM, CUTDET_S2_TWO_WAVES, CUTDET_RESIZE_ROWS = 0 or 1).
+ * CD_OPT_SPLIT_TWO_WAVES and CD_OPT_RESIZE_ROWS apply to every entry point that runs those kernels, not
+ * only to the range call.
  *   CD_OPT_RANGE_BY_STAGE   0 (default): whole batches alternate between the two streams.  1: block 1
  *                           of every batch on one stream, blocks 2 + 3 on the other.
  *   CD_OPT_FUSE_BLOCKS12    CD_BF16_SPLIT handles only.  1: the resize pass writes the first block's
@@ -177,8 +179,19 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
  *                           measured geometries - the fused kernel fills every CU's registers and LDS,
  *                           so nothing overlaps with it.
  *   CD_OPT_RANGE_ONE_STREAM 1: everything on the caller's stream (for measurements: per-stage event
- *                           times are then the kernels' own durations). */
-enum { CD_OPT_RANGE_BY_STAGE = 0, CD_OPT_FUSE_BLOCKS12 = 1, CD_OPT_RANGE_ONE_STREAM = 2, CD_OPT_COUNT = 3 };
+ *                           times are then the kernels' own durations).
+ *   CD_OPT_SPLIT_TWO_WAVES  CD_BF16_SPLIT handles only.  1: block 2 runs two waves per SIMD (256 registers
+ *                           and one patch buffer each).  0 (default): one wave per SIMD with double-buffered
+ *                           patches, the faster of the two on the measured geometries (the two-wave
+ *                           kernel waits for its weights, which a second wave's traffic delays in L2).
+ *   CD_OPT_RESIZE_ROWS      The stand-alone resize (cd_resize_u8, and the resize pass of the range call).
+ *                           0 (default): one thread per output pixel reads its taps from global memory; no
+ *                           LDS, so its workgroups find room on a CU beside the convolution kernels'.
+ *                           1: one workgroup per output row stages the two source rows in LDS (needs
+ *                           16-byte aligned rows; used anyway when the default kernel does not apply: output
+ *                           widths that are not a multiple of 4, rows shorter than 8 bytes). */
+enum { CD_OPT_RANGE_BY_STAGE = 0, CD_OPT_FUSE_BLOCKS12 = 1, CD_OPT_RANGE_ONE_STREAM = 2, CD_OPT_SPLIT_TWO_WAVES = 3,
+       CD_OPT_RESIZE_ROWS = 4, CD_OPT_COUNT = 5 };
 int cd_set_option(cd_handle* h, int option, int value);
 
 /* cd_forward_u8 for callers that cannot allocate device memory (code under HIP graph capture, tight

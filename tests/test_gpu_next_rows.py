@@ -292,6 +292,34 @@ def test_resize_u8_is_bit_exact(engine, h, w):
     assert got.shape == want.shape and (got == want).all()
 
 
+@pytest.mark.parametrize("h,w,resize", [(1080, 1920, 320), (90, 161, 320), (360, 640, 320), (200, 333, 100), (64, 96, 48),
+                                        (50, 77, 30), (9, 2, 4)])
+def test_resize_kernels_agree_on_any_row_layout(h, w, resize):
+    """The resize has two kernels: taps straight from global memory (default; no alignment needs) and source
+    rows staged in LDS (CD_OPT_RESIZE_ROWS).  Both give the oracle's bytes - bilinear, point-sampled and 2x2
+    box geometries, right-edge taps, a last row group that is not full, output widths that are not a multiple
+    of 4 and rows shorter than 8 bytes (where the default kernel hands over) - also on views whose rows start
+    at odd addresses and are padded."""
+    from cutdet import api
+    from cutdet.engine import Engine
+    from oracle import preprocess, synth
+    base = api.default_engine("cuda:0", "f32")
+    rows = Engine(api.default_blob(), base.device, "f32")
+    rows.set_option("resize_rows", 1)
+    frames = synth.clip(SEED + 5, [0, 1, 2, 1], h, w)
+    nh, nw = preprocess.output_size(h, w, resize)
+    want = np.stack([preprocess.resize_linear_u8(f, nh, nw) for f in frames])
+    dev = torch.from_numpy(frames).to(base.device)
+    wide = torch.zeros((4, h + 1, w + 7, 3), dtype=torch.uint8, device=base.device)
+    view = wide[:, 1:, 3:w + 3]
+    view.copy_(dev)
+    for eng in (base, rows):
+        for src in (dev, view):
+            got = eng.resize_u8(src, resize).cpu().numpy()
+            assert got.shape == want.shape and (got == want).all()
+    rows.close()
+
+
 @pytest.mark.parametrize("h,w,dtype", [(1080, 1920, "f32"), (180, 320, "f32"), (1080, 1920, "bf16_split"), (180, 320, "bf16")])
 def test_overlapped_resize_pipeline_matches_the_fused_call(h, w, dtype):
     """classify_range with the resize on a second stream (three buffer reuses, a short last batch)
@@ -382,6 +410,33 @@ def test_fused_blocks_1_and_2_give_the_bits_of_the_separate_kernels(h, w, bs, n)
     from cutdet import _lib
     assert _lib.lib.cd_set_option(eng._h, 9, 1) == _lib.CD_EINVAL and _lib.lib.cd_set_option(eng._h, 1, 2) == _lib.CD_EINVAL
     eng.close()
+
+
+@pytest.mark.parametrize("h,w,n", [(720, 1280, 300), (180, 320, 77), (480, 640, 130), (90, 160, 9)])
+def test_split_block2_two_waves_per_simd_gives_the_bits_of_the_one_wave_kernel(h, w, n):
+    """CD_OPT_SPLIT_TWO_WAVES: split bf16 block 2 with two waves per SIMD (one patch buffer, copied over
+    during a unit's last step, rows of a step one after the other).  Same logits bit for bit as the default
+    one-wave kernel, for batches that fill the grid many times over and for ones smaller than it, repeated calls."""
+    from cutdet import api, synth as csynth
+    from cutdet.engine import Engine
+    from cutdet.pipeline import ClipClassifier
+    one = api.default_engine("cuda:0", "bf16_split")
+    base = Engine(api.default_blob(), one.device, "bf16_split")
+    base.set_option("split_two_waves", 1)
+    cl = csynth.classes_from_runs(csynth.run_table(n, SEED + 3))
+    frames = base.synth_frames(torch.tensor(cl, dtype=torch.uint8, device=base.device), h, w, SEED + 3)
+    want = ClipClassifier(one, n)
+    want.classify_range(frames, 0, 128, overlap=False)
+    got = ClipClassifier(base, n)
+    for bs in (128, 7, n):
+        got.logits.fill_(float("nan"))
+        got.classify_range(frames, 0, bs, overlap=False)
+        assert torch.equal(got.logits, want.logits) and torch.equal(got.cls, want.cls) and torch.equal(got.maxv, want.maxv), bs
+    got.logits.fill_(float("nan"))
+    got.classify_range(frames, 0, 64)                 # the two-stream range entry
+    assert torch.equal(got.logits, want.logits)
+    assert got.cls.cpu().tolist() == cl
+    base.close()
 
 
 def test_range_entry_rejects_bad_arguments(engine):

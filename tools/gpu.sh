@@ -12,6 +12,9 @@
 #   tools/gpu.sh stats NAME [bench args]   rocprofv3 --kernel-trace --stats of bench.py (per-kernel durations)
 #   tools/gpu.sh trace NAME [bench args]   kernel trace of bench.py + tools/trace_overlap.py (timeline, overlap)
 #   tools/gpu.sh py <script> [args]         a python tool under a time limit (tools/*.py)
+#   tools/gpu.sh ablate [range_stages args] omission ablation of the range call: tools/range_stages.py with each stage
+#                                           (and pairs of stages) left out - needs the timing-experiment build
+#                                           `make -C cut-detection_amd/csrc variant NAME=skip FLAGS=-DCD_EXP_SKIP`
 #
 # Every GPU step runs under its own time limit and the script stops at the first failure.
 set -o pipefail
@@ -36,6 +39,14 @@ PY
 }
 
 case "$MODE" in
+ablate)
+  LIBV=$PWD/cut-detection_amd/lib/variants/libcutdet_skip.so
+  [ -f "$LIBV" ] || { echo "build the skip variant first (see the header of this script)"; exit 1; }
+  for m in 0 1 2 4 8 3 6 5; do     # 1 resize pass, 2 block 1, 4 block 2, 8 block 3 + head
+    echo "== stages left out: mask $m"
+    CUTDET_SKIP=$m CUTDET_LIB=$LIBV timeout -k 10 300 python3 -u tools/range_stages.py "$@" | grep "range entry" || exit 1
+  done
+  ;;
 tests)
   T="${@:-tests}"
   timeout -k 10 1100 python3 -u -m pytest $T -x -q --timeout 600 --timeout-method thread -m gpu > gpurun_out/gputests.log 2>&1 \
