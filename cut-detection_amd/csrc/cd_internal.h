@@ -166,7 +166,7 @@ int launch_conv12_split(const cd_handle* h, const Workspace& ws, const uint8_t* 
 int launch_conv1_f32(const cd_handle* h, const Workspace& ws, const float* x, int n, const Geometry& g, hipStream_t s);
 int launch_conv1_u8(const cd_handle* h, const Workspace& ws, const ResizeTables& rt, const uint8_t* src, int n, int H0,
                     int W0, int64_t row_stride, int64_t frame_stride, int chan_order, const Geometry& g, hipStream_t s);
-int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s);
+int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s, bool far_weights = false);
 int init_conv3_head();
 int init_conv2_split2();     // same, for the two-waves-per-SIMD block-2 kernel of split bf16
 int launch_conv3_head(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, float* logits, float* maxv,

@@ -127,7 +127,11 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     // The kernels build the two B operands {hi x 4, hi x 4} and {lo x 4, lo x 4} (each half meets one half of
     // the activation cell) in registers: stored that way the weights would be twice the bytes, and block 2's
     // 83 KB already stream from L2 once per wave tile.
+#ifdef CD_S2_WDUP
+    const size_t o_w2s = section(27 * 3 * 64 * 8), o_w3s = section(27 * 3 * 64 * 8);
+#else
     const size_t o_w2s = section(27 * 3 * 64 * 4), o_w3s = section(27 * 3 * 64 * 4);
+#endif
     for (int l = 1; l < 3; ++l) {
         const size_t src = l == 1 ? o_w2 : o_w3, dst = l == 1 ? o_w2s : o_w3s;
         uint16_t* d = reinterpret_cast<uint16_t*>(&img[dst]);
@@ -140,9 +144,15 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
                     float hf;
                     std::memcpy(&hf, &hb, 4);
                     const uint16_t lo = bf16_rne(w - hf);
+#ifdef CD_S2_WDUP
+                    uint16_t* ph = d + (f * 2 * 64 + lane) * 8, *pl = d + ((f * 2 + 1) * 64 + lane) * 8;
+                    ph[e] = ph[4 + e] = hi;
+                    pl[e] = pl[4 + e] = lo;
+#else
                     uint16_t* cell = d + (f * 64 + lane) * 8;
                     cell[e] = hi;
                     cell[4 + e] = lo;
+#endif
                 }
     }
     // block 1 in bf16: fragment (ky, nt), lane (kx = lane>>4, col): W[16nt+col][ci = e][ky][kx], zero for kx = 3 / e = 3
@@ -765,7 +775,11 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     // matrix-bound classification measured faster than beside two (1080p: 402 k against 363 k
     // frames/s), small frames the other way round (320x180: 424 k against 442 k); the bf16 arithmetics,
     // whose kernels are short, gain from the second classification stream at every size
-    const bool two_cls = !(two_pass && h->dtype == CD_F32 && (int64_t)H0 * W0 * 3 > (2 << 20));
+    const bool large_frames = (int64_t)H0 * W0 * 3 > (2 << 20);
+    const bool two_cls = !(two_pass && h->dtype == CD_F32 && large_frames);
+    // split bf16 beside a resize pass that saturates HBM: block 2 asks for its weights 8 steps ahead instead
+    // of 2 (interleaved A/B at 1080p: +2.9 %; at 720p and 320x180, where nothing streams beside it, -0.5 %)
+    const bool far_weights = two_pass && !one_stream && large_frames;
     hipStream_t pre = one_stream ? s : h->side_pre;
     for (int64_t i = 0; i < nb; ++i) {
         const int64_t a = i * batch;
@@ -820,7 +834,7 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
             CD_HIP(hipEventRecord(h->ev_a1ready[par], st1));
             CD_HIP(hipStreamWaitEvent(st2, h->ev_a1ready[par], 0));
         }
-        CD_SKIP_IF(4) { StageTimer t(h, CD_STAGE_CONV2, st2); if ((rc = launch_conv2(h, ws, k, g, st2))) return rc; }
+        CD_SKIP_IF(4) { StageTimer t(h, CD_STAGE_CONV2, st2); if ((rc = launch_conv2(h, ws, k, g, st2, far_weights))) return rc; }
         if (mode == 1) CD_HIP(hipEventRecord(h->ev_a1free[par], st2));
         StageTimer t(h, CD_STAGE_CONV3_HEAD, st2);
         CD_SKIP_IF(8)

@@ -50,14 +50,21 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 // is only the splitting itself: |v - (hi + lo)| <= 2^-17 |v|.
 constexpr int kF32 = 0, kBF16 = 1, kS2 = 2;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifdef CD_S2_WDUP                     // measurement build: B operands stored ready-made (twice the bytes, two loads, no moves)
+struct SplitB { u32x4 h, l; };
+#else
 struct SplitB { u32x4 v; };          // weights of one (step, n-tile) as loaded: {w_hi x 4, w_lo x 4} per lane
+#endif
 template <int P> struct Prec;
 template <> struct Prec<kF32> {
     typedef float elem; typedef f32x4 frag; typedef f32x4 bfrag;
     static constexpr int kSub = 4;          // MFMAs per fragment pair
     static constexpr int kEs = 4;           // bytes per element
     static constexpr int kWBytes = 16;      // bytes of one lane's B fragment
-    static constexpr int kBDist = 1;        // block 2: steps a weight fragment is requested ahead of its use
+#ifndef CD_F32_BDIST
+#define CD_F32_BDIST 1
+#endif
+    static constexpr int kBDist = CD_F32_BDIST;   // block 2: steps a weight fragment is requested ahead of its use
     static constexpr int kBLoads = 3;       // block 2: buffer loads per step
 };
 template <> struct Prec<kBF16> {
@@ -72,12 +79,20 @@ template <> struct Prec<kS2> {
     typedef uint32_t elem; typedef u32x4 frag; typedef SplitB bfrag;   // element = one channel's (hi, lo), by size only
     static constexpr int kSub = 2;
     static constexpr int kEs = 4;
+#ifdef CD_S2_WDUP
+    static constexpr int kWBytes = 32;
+#else
     static constexpr int kWBytes = 16;
+#endif
 #ifndef CD_S2_BDIST
 #define CD_S2_BDIST 2
 #endif
     static constexpr int kBDist = CD_S2_BDIST;   // a step is only ~860 cycles here: one step ahead does not cover an L2 round trip
+#ifdef CD_S2_WDUP
+    static constexpr int kBLoads = 6;
+#else
     static constexpr int kBLoads = 3;
+#endif
 };
 
 // Weight fragments are read through a buffer descriptor: the address is one per-lane VGPR
@@ -96,8 +111,13 @@ __device__ __forceinline__ typename Prec<P>::bfrag load_frag(__amdgpu_buffer_rsr
 #ifdef CD_EXP_WHOT
         idx &= 1;                     // timing experiment: every weight load hits L1 (wrong results)
 #endif
+#ifdef CD_S2_WDUP
+        return SplitB{__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 2048, 0)),
+                      __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 2048 + 1024, 0))};
+#else
         const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
         return SplitB{v};
+#endif
     } else
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, idx * 1024, 0));
 }
@@ -111,11 +131,16 @@ template <int P>
 __device__ __forceinline__ f32x4 mfma_frag(const typename Prec<P>::frag& a, const typename Prec<P>::bfrag& b, int e,
                                            f32x4 c) {
     if constexpr (P == kBF16) return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+#ifdef CD_S2_WDUP
+    else if constexpr (P == kS2)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, e == 0 ? b.l : b.h), c, 0, 0, 0);
+#else
     else if constexpr (P == kS2)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                        __builtin_bit_cast(bf16x8, e == 0 ? u32x4{b.v[2], b.v[3], b.v[2], b.v[3]}
                                                                                          : u32x4{b.v[0], b.v[1], b.v[0], b.v[1]}),
                                                        c, 0, 0, 0);
+#endif
     else return mfma4(a[e], b[e], c);
 }
 // two fp32 values -> two bf16 (round to nearest even) in one dword, `lo` in the low half
@@ -1046,17 +1071,17 @@ __device__ __forceinline__ void conv2_dma_group(const char* src, typename Prec<B
 // zero as its C operand, so the accumulators are defined and consumed inside one tile body and
 // never cross the loop edge (the compiler otherwise permutes all 108 of them through VGPRs once
 // per unit).
-template <int G, int BF>
+template <int G, int BF, int KBD>
 __device__ __forceinline__ void conv2_unit(const typename Prec<BF>::elem* bufs, int mine_off, int other_off,
                                            const char* next_src, const int (&rel)[G2<BF>::kDma],
                                            const int (&base)[3], __amdgpu_buffer_rsrc_t wr, int lane,
                                            typename Prec<BF>::frag (&a)[2][3][3],
-                                           typename Prec<BF>::bfrag (&b)[Prec<BF>::kBDist + 1][3],
+                                           typename Prec<BF>::bfrag (&b)[KBD + 1][3],
                                            f32x4 (&acc)[3][3][3], unsigned long long* st = nullptr) {
     typedef typename Prec<BF>::frag frag;
     typedef typename Prec<BF>::elem elem;
     constexpr int kM = 27 * Prec<BF>::kSub;      // MFMAs per step
-    constexpr int kBD = Prec<BF>::kBDist, kNB = kBD + 1;
+    constexpr int kBD = KBD, kNB = kBD + 1;
     if (st && lane == 0) st[9] = __builtin_amdgcn_s_memrealtime();
     // The patch copy issued in step 0 of the previous unit must have landed.  VMEM completes in issue
     // order, so it is enough to wait for everything but the weight loads of the last kBD - 1 steps
@@ -1173,7 +1198,8 @@ __device__ __forceinline__ void conv2_epilogue(float* scratch, const f32x4 (&acc
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int BF>
+// KBD: how many steps ahead of their use the weight fragments are requested (KBD + 1 register sets).
+template <int BF, int KBD = Prec<BF>::kBDist>
 __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem* __restrict__ in,
                                                    typename Prec<BF>::elem* __restrict__ out,
                                                    const void* __restrict__ wfrag,
@@ -1235,7 +1261,7 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
     Conv2Tile<BF> nxt = locate(next_id);
     // everything the first step needs from global memory is requested together: the patch copy,
     // step 0's weight fragments and the affine terms share one round trip
-    constexpr int kBD = Prec<BF>::kBDist;
+    constexpr int kBD = KBD;
     frag a[2][3][3];
     typename Prec<BF>::bfrag b[kBD + 1][3];
     f32x4 acc[3][3][3];
@@ -1273,21 +1299,25 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
         for (int s0 = 0; s0 < kBD; ++s0)
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
+                #ifdef CD_S2_WDUP
+                if constexpr (BF == kS2) { asm volatile("" : "+v"(b[s0][nt].h)); asm volatile("" : "+v"(b[s0][nt].l)); }
+#else
                 if constexpr (BF == kS2) asm volatile("" : "+v"(b[s0][nt].v));
+#endif
                 else asm volatile("" : "+v"(b[s0][nt]));
             }
 #ifdef CD_DIAG
         unsigned long long* stp = (BF == CD_DIAG_P && blockIdx.x < 200 && nstamp == 14) ? stamps + 6400 : nullptr;   // third tile
-        conv2_unit<0, BF>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc, stp);
+        conv2_unit<0, BF, KBD>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc, stp);
         CD_STAMP();
-        conv2_unit<1, BF>(bufs, second, first, cur.src + 2 * kGroupBytes, rel, base, wr, lane, a, b, acc, stp ? stp + 10 : nullptr);
+        conv2_unit<1, BF, KBD>(bufs, second, first, cur.src + 2 * kGroupBytes, rel, base, wr, lane, a, b, acc, stp ? stp + 10 : nullptr);
         CD_STAMP();
-        conv2_unit<2, BF>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc, stp ? stp + 20 : nullptr);
+        conv2_unit<2, BF, KBD>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc, stp ? stp + 20 : nullptr);
         CD_STAMP();
 #else
-        conv2_unit<0, BF>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc);
-        conv2_unit<1, BF>(bufs, second, first, cur.src + 2 * kGroupBytes, rel, base, wr, lane, a, b, acc);
-        conv2_unit<2, BF>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc);
+        conv2_unit<0, BF, KBD>(bufs, first, second, cur.src + kGroupBytes, rel, base, wr, lane, a, b, acc);
+        conv2_unit<1, BF, KBD>(bufs, second, first, cur.src + 2 * kGroupBytes, rel, base, wr, lane, a, b, acc);
+        conv2_unit<2, BF, KBD>(bufs, first, second, nxt.src, rel, base, wr, lane, a, b, acc);
 #endif
         // `first` was last read one step ago; the next tile's first unit copies into it only after
         // the epilogue's final LDS wait
@@ -1319,7 +1349,11 @@ __global__ __launch_bounds__(64) void conv2_kernel(const typename Prec<BF>::elem
 
 int launch_conv2_split2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s);
 
-int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s) {
+// far_weights: split bf16 only - the instance that requests its weights kS2FarWeights steps ahead instead of
+// kBDist.  Worth its 100 extra registers only while another stream saturates HBM (the range call's resize
+// pass at 1080p: +2.9 %; without such a stream 0.5 % slower), so the caller says when.
+constexpr int kS2FarWeights = 8;
+int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry& g, hipStream_t s, bool far_weights) {
     const int tiles_y = (g.h2 + 3) / 4, tiles_x = (kW2 + 3) / 4;
     const int total = (int)xcd_grid(n, tiles_x * tiles_y);
     // persistent single-wave workgroups: one per SIMD in fp32 (the wave needs 308 registers and keeps
@@ -1333,6 +1367,10 @@ int launch_conv2(const cd_handle* h, const Workspace& ws, int n, const Geometry&
                            (const void*)h->p.w2b, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     else if (h->dtype == CD_BF16_SPLIT && h->opt[CD_OPT_SPLIT_TWO_WAVES])
         return launch_conv2_split2(h, ws, n, g, s);
+    else if (h->dtype == CD_BF16_SPLIT && far_weights)
+        hipLaunchKernelGGL((conv2_kernel<kS2, kS2FarWeights>), dim3((unsigned)grid), dim3(64), 0, s,
+                           reinterpret_cast<const uint32_t*>(ws.act1), reinterpret_cast<uint32_t*>(ws.act2),
+                           (const void*)h->p.w2s, h->p.post + 3 * kC, n, g.h1, g.h2, tiles_x, tiles_y, total);
     else if (h->dtype == CD_BF16_SPLIT)
         hipLaunchKernelGGL(conv2_kernel<kS2>, dim3((unsigned)grid), dim3(64), 0, s,
                            reinterpret_cast<const uint32_t*>(ws.act1), reinterpret_cast<uint32_t*>(ws.act2),
