@@ -426,8 +426,15 @@ int env_option(const char* name, int fallback) {
 int ensure_range_state(cd_handle* h) {
     if (h->side_cls) return CD_OK;
     hipStream_t a = nullptr, b = nullptr;
+#ifdef CD_EXP_ENV        // measurement build: stream priorities from the environment (-1 high, 0 normal, 1 low)
+    const char* pa = std::getenv("CUTDET_X_CLS_PRIO");
+    const char* pb = std::getenv("CUTDET_X_PRE_PRIO");
+    CD_HIP(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, pa ? std::atoi(pa) : 0));
+    if (hipStreamCreateWithPriority(&b, hipStreamNonBlocking, pb ? std::atoi(pb) : 0) != hipSuccess) {
+#else
     CD_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) {
+#endif
         (void)hipStreamDestroy(a);
         set_error("cd_forward_u8_range: cannot create a stream");
         return CD_EHIP;
@@ -776,7 +783,11 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     // frames/s), small frames the other way round (320x180: 424 k against 442 k); the bf16 arithmetics,
     // whose kernels are short, gain from the second classification stream at every size
     const bool large_frames = (int64_t)H0 * W0 * 3 > (2 << 20);
+#ifdef CD_EXP_ENV
+    const bool two_cls = std::getenv("CUTDET_X_ONE_CLS") ? false : !(two_pass && h->dtype == CD_F32 && large_frames);
+#else
     const bool two_cls = !(two_pass && h->dtype == CD_F32 && large_frames);
+#endif
     // split bf16 beside a resize pass that saturates HBM: block 2 asks for its weights 8 steps ahead instead
     // of 2 (interleaved A/B at 1080p: +2.9 %; at 720p and 320x180, where nothing streams beside it, -0.5 %)
     const bool far_weights = two_pass && !one_stream && large_frames;
