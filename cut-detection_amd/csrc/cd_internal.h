@@ -121,6 +121,7 @@ struct cd_handle {
     // cd_forward_u8_range: side streams (classification of every other batch; stand-alone resize) and
     // the events that fork from / join into the caller's stream and hand resized batches over
     hipStream_t side_cls, side_pre;
+    bool own_side_streams;  // false: the device's shared pair (the usual case), not destroyed with the handle
     hipEvent_t ev_fork, ev_join, ev_ready[3], ev_free[3], ev_a1ready[2], ev_a1free[2];
     uint8_t* small;         // resized frames of up to three batches in flight: [3][small_frames][net_h][256][3]
     size_t small_bytes;     // bytes of one of the three slots

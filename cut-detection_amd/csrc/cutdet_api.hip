@@ -422,22 +422,51 @@ int env_option(const char* name, int fallback) {
     return e && (e[0] == '0' || e[0] == '1') && !e[1] ? e[0] - '0' : fallback;
 }
 
+// The two side streams of cd_forward_u8_range exist once per device and are shared by every handle on it: a
+// process has few hardware queues (4 by default) and streams are dealt onto them in creation order, so a
+// pair per handle soon puts two streams of ONE call on the same queue (measured: the bench's second
+// handle 3 % slower than the same work in a process of its own).  They live until the process ends.
+struct SideStreams { hipStream_t cls = nullptr, pre = nullptr; };
+SideStreams g_side[kMaxDevices];
+std::mutex g_side_mutex;
+
+static int create_side_streams(hipStream_t* a, hipStream_t* b) {
+#ifdef CD_EXP_ENV        // measurement build: stream priorities from the environment (-1 high, 0 normal, 1 low)
+    const char* pa = std::getenv("CUTDET_X_CLS_PRIO");
+    const char* pb = std::getenv("CUTDET_X_PRE_PRIO");
+    CD_HIP(hipStreamCreateWithPriority(a, hipStreamNonBlocking, pa ? std::atoi(pa) : 0));
+    if (hipStreamCreateWithPriority(b, hipStreamNonBlocking, pb ? std::atoi(pb) : 0) != hipSuccess) {
+#else
+    CD_HIP(hipStreamCreateWithFlags(a, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(b, hipStreamNonBlocking) != hipSuccess) {
+#endif
+        (void)hipStreamDestroy(*a);
+        set_error("cd_forward_u8_range: cannot create a stream");
+        return CD_EHIP;
+    }
+    return CD_OK;
+}
+
 // Streams and events of cd_forward_u8_range, created on first use (with the handle's device current).
 int ensure_range_state(cd_handle* h) {
     if (h->side_cls) return CD_OK;
     hipStream_t a = nullptr, b = nullptr;
-#ifdef CD_EXP_ENV        // measurement build: stream priorities from the environment (-1 high, 0 normal, 1 low)
-    const char* pa = std::getenv("CUTDET_X_CLS_PRIO");
-    const char* pb = std::getenv("CUTDET_X_PRE_PRIO");
-    CD_HIP(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, pa ? std::atoi(pa) : 0));
-    if (hipStreamCreateWithPriority(&b, hipStreamNonBlocking, pb ? std::atoi(pb) : 0) != hipSuccess) {
-#else
-    CD_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-    if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) {
-#endif
-        (void)hipStreamDestroy(a);
-        set_error("cd_forward_u8_range: cannot create a stream");
-        return CD_EHIP;
+    if (h->device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(g_side_mutex);
+        SideStreams& ss = g_side[h->device];
+        if (!ss.cls) {
+            int rc = create_side_streams(&a, &b);
+            if (rc) return rc;
+            ss.cls = a;
+            ss.pre = b;
+        }
+        a = ss.cls;
+        b = ss.pre;
+        h->own_side_streams = false;
+    } else {
+        int rc = create_side_streams(&a, &b);
+        if (rc) return rc;
+        h->own_side_streams = true;
     }
     hipEvent_t* ev[12] = {&h->ev_fork, &h->ev_join, &h->ev_ready[0], &h->ev_ready[1], &h->ev_ready[2],
                           &h->ev_free[0], &h->ev_free[1], &h->ev_free[2], &h->ev_a1ready[0], &h->ev_a1ready[1],
@@ -554,8 +583,10 @@ void cd_destroy(cd_handle* h) {
     }
     if (h->small) (void)hipFree(h->small);
     if (h->cells) (void)hipFree(h->cells);
-    if (h->side_cls) (void)hipStreamDestroy(h->side_cls);
-    if (h->side_pre) (void)hipStreamDestroy(h->side_pre);
+    if (h->own_side_streams) {
+        if (h->side_cls) (void)hipStreamDestroy(h->side_cls);
+        if (h->side_pre) (void)hipStreamDestroy(h->side_pre);
+    }
     for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_ready[0], h->ev_ready[1], h->ev_ready[2], h->ev_free[0],
                          h->ev_free[1], h->ev_free[2], h->ev_a1ready[0], h->ev_a1ready[1], h->ev_a1free[0],
                          h->ev_a1free[1]})
@@ -790,7 +821,11 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
 #endif
     // split bf16 beside a resize pass that saturates HBM: block 2 asks for its weights 8 steps ahead instead
     // of 2 (interleaved A/B at 1080p: +2.9 %; at 720p and 320x180, where nothing streams beside it, -0.5 %)
+#ifdef CD_EXP_NO_FAR      // measurement build
+    const bool far_weights = false;
+#else
     const bool far_weights = two_pass && !one_stream && large_frames;
+#endif
     hipStream_t pre = one_stream ? s : h->side_pre;
     for (int64_t i = 0; i < nb; ++i) {
         const int64_t a = i * batch;

@@ -153,13 +153,16 @@ int cd_forward_u8(cd_handle* h, const uint8_t* src, int n, int H0, int W0,
  * chan_order, net_h, net_w as in cd_forward_u8; logits [n][3], maxv [n], argmax [n] (the last two may
  * be NULL) are written at the frames' own rows.  Results are bit-identical to calling cd_forward_u8
  * batch by batch.  What the single-batch call cannot do: consecutive batches alternate between two
- * activation workspaces, the caller's stream and a stream the handle owns, so the start-up, tail and
+ * activation workspaces, the caller's stream and a side stream, so the start-up, tail and
  * per-frame serial phases of one batch's kernels fill with the other batch's work; and for source
  * geometries that need a real resize (not a point sample) the resize of the batches ahead runs as a
  * separate memory-bound pass on a third stream beside the matrix-bound classification.  The call
  * forks from and joins back into `stream`: everything it queued is ordered before whatever the
  * caller queues on `stream` afterwards, and it does not synchronise in the steady state (first use
- * creates the two streams and the second workspace).  n <= batch is exactly cd_forward_u8. */
+ * creates the second workspace).  The two side streams exist once per device and are shared by every
+ * handle on it (a process has few hardware queues; a pair per handle would put streams of one call on
+ * the same queue): range calls of different handles that overlap in time on one device stay correct,
+ * their side-stream work is queued one call behind the other.  n <= batch is exactly cd_forward_u8. */
 int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, int H0, int W0,
                         int64_t row_stride, int64_t frame_stride, int chan_order,
                         int net_h, int net_w,
