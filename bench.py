@@ -104,6 +104,10 @@ def parse(argv=None):
     ap.add_argument("--independent-clips", action="store_true",
                     help="multi-GPU: the headline itself is one clip per rank (no gather, no process group at all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--f32-block1-fp32-mfma", action="store_true",
+                    help="fp32 only: block 1 on the fp32 matrix instructions too (default: the frame's bytes times three "
+                         "exact bfloat16 weight terms on the bf16 matrix pipe; the default run reports this variant as "
+                         "the fp32_mfma_block1 object)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="only the headline (and its roofline pass): no config4 / strong_200k / independent_clips legs")
     ap.add_argument("--no-overlap", action="store_true",
@@ -410,6 +414,10 @@ def block2_roofline(leg, dtype, height, width, batch, fps_per_gpu):
         "issued_frac_of_peak": round(achieved * (84.0 / 85.0) / peak, 4),
         "whole_net_tflops": round(FLOPS_FRAME * fps_per_gpu / 1e12, 2),
         "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * fps_per_gpu / 1e12 / peak, 4),
+        "whole_net_note": ("algorithmic FLOPs of all three blocks over the fp32 matrix peak; block 1 (95.6 of 283.4 MFLOP per "
+                           "frame) runs on the bf16 matrix pipe with exact three-term weights unless --f32-block1-fp32-mfma, so "
+                           "this ratio is not bounded by 1; fp32_mfma_block1 has it with every block on the fp32 pipe")
+                          if dtype == "f32" else None,
         "hbm_compulsory_GBps": round(bytes_frame * fps_per_gpu / 1e9, 2),
         "hbm_frac_of_peak": round(bytes_frame * fps_per_gpu / 1e9 / PEAK_HBM_GBS, 5),
     }
@@ -467,6 +475,8 @@ def main():
     from cutdet import api
 
     eng = api.default_engine(dev, args.dtype)
+    if args.f32_block1_fp32_mfma:
+        eng.set_option("f32_block1_fp32_mfma", 1)
     strong = args.total_frames is not None
     total = args.total_frames if strong else world * args.clip_frames
     gather = world > 1 and not args.independent_clips
@@ -482,6 +492,23 @@ def main():
         cpu_sample = job.frames_buffer(b0 - a0, args.height, args.width)[: (2 + nb) * 128].cpu()   # chunk 0 is loaded
     default_run = (args.dtype, args.height, args.width, args.batch) == ("f32", H0, W0, BATCH) and not strong \
         and not args.independent_clips and not args.no_extra_legs
+    if default_run and world == 1 and not args.f32_block1_fp32_mfma:
+        # ---- the headline configuration once more with block 1 on the fp32 matrix instructions as well
+        from cutdet.engine import Engine
+        eng_s = Engine(api.default_blob(), dev, "f32")
+        eng_s.set_option("f32_block1_fp32_mfma", 1)
+        leg = run_leg(job, eng_s, total=total, gather=False, steps=args.leg_steps + 2, warmup=args.leg_warmup + 1,
+                      height=args.height, width=args.width, batch=args.batch, resident_frames=args.resident_frames)
+        extra["fp32_mfma_block1"] = {
+            "value": round(leg["fps"], 1), "unit": "frames/s", "ms_per_step": round(leg["ms_per_step"], 4),
+            "steps": args.leg_steps + 2, "warmup": args.leg_warmup + 1,
+            "what": "the headline workload with block 1 on v_mfma_f32_16x16x4_f32 like blocks 2 and 3 "
+                    "(CD_OPT_F32_BLOCK1_FP32_MFMA); logits differ from the default's in the last bits, both within "
+                    "1e-5 of the reference's",
+            "whole_net_tflops": round(FLOPS_FRAME * leg["fps"] / 1e12, 2),
+            "whole_net_frac_of_mfma_peak": round(FLOPS_FRAME * leg["fps"] / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        }
+        eng_s.close()
     if default_run and world == 1:
         # ---- configuration 4: 1920x1080, split-bf16 matrix cores, batch 512
         eng4 = api.default_engine(dev, C4["dtype"])
@@ -542,7 +569,11 @@ def main():
         fps = head["fps"]
         merged = head["result"]["merged"]
         net_h = head["net_h"]
-        arith = {"f32": "fp32", "bf16": "bf16-matrix-core", "bf16_split": "split-bf16 (hi+lo, 4 products) matrix-core"}[args.dtype]
+        arith = {"f32": "fp32 (blocks 2-3 on v_mfma_f32_16x16x4_f32; block 1 " +
+                        ("on it too" if args.f32_block1_fp32_mfma else
+                         "multiplies the frame's bytes with the fp32 weights as three exact bfloat16 terms on "
+                         "v_mfma_f32_16x16x32_bf16: exact products, fp32 accumulation") + ")",
+                 "bf16": "bf16-matrix-core", "bf16_split": "split-bf16 (hi+lo, 4 products) matrix-core"}[args.dtype]
         out = {
             "metric": f"frames/sec classified+segmented, {args.width}x{args.height} RGB",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,

@@ -45,7 +45,7 @@ void bn_affine(const float* g, const float* beta, const float* mu, const float* 
     }
 }
 
-struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b, w1b, w2s, w3s, w1s; };
+struct ParamOffsets { size_t w1, w2, w3, post, fc0w, fc0p, fc1w, fc1b, lut, w2b, w3b, w1b, w2s, w3s, w1s, w1x; };
 
 // float -> bfloat16 bits, round to nearest even (what v_cvt_pk_bf16_f32 and torch's .bfloat16() do)
 static uint16_t bf16_rne(float f) {
@@ -188,6 +188,26 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
                         cell[4 + e] = bf16_rne(w - hf);
                     }
     }
+    // the third term of the same weights, {lo2(w'[ci=0..2]), 0, 0, 0, 0, 0}: hi + lo + lo2 == w' exactly (3 x 8 mantissa
+    // bits; the remainder after each term is computed exactly in fp32)
+    const size_t o_w1x = section(9 * 64 * 4);
+    {
+        uint16_t* d = reinterpret_cast<uint16_t*>(&img[o_w1x]);
+        const uint16_t* two = reinterpret_cast<const uint16_t*>(&img[o_w1s]);
+        auto as_float = [](uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        for (int ky = 0; ky < 3; ++ky)
+            for (int nt = 0; nt < 3; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int kx = lane >> 4, oc = 16 * nt + (lane & 15);
+                        const float w = (kx < 3 && e < 3) ? cv[0].w[oc * 27 + e * 9 + ky * 3 + kx] / 255.0f : 0.f;
+                        const uint16_t* c2 = two + ((ky * 3 + nt) * 64 + lane) * 8;
+                        const float rest = (w - as_float(c2[e])) - as_float(c2[4 + e]);
+                        uint16_t* cell = d + ((ky * 3 + nt) * 64 + lane) * 8;
+                        cell[e] = bf16_rne(rest);
+                        cell[4 + e] = 0;
+                    }
+    }
     for (int l = 0; l < 3; ++l) {
         float* p = &img[o_post + (size_t)l * 3 * kC];
         std::memcpy(p, cv[l].b, kC * sizeof(float));
@@ -206,7 +226,7 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
     std::memcpy(&img[o_fc1b], fc1b, kOut * sizeof(float));
     for (int k = 0; k < 256; ++k) img[o_lut + k] = (float)k / 255.0f;   // data.py:227 divides, it does not scale
 
-    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b, o_w1b, o_w2s, o_w3s, o_w1s};
+    *off = ParamOffsets{o_w1, o_w2, o_w3, o_post, o_fc0w, o_fc0p, o_fc1w, o_fc1b, o_lut, o_w2b, o_w3b, o_w1b, o_w2s, o_w3s, o_w1s, o_w1x};
     return img;
 }
 
@@ -535,6 +555,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->opt[CD_OPT_RANGE_ONE_STREAM] = env_option("CUTDET_RANGE_ONE_STREAM", 0);
     h->opt[CD_OPT_SPLIT_TWO_WAVES] = env_option("CUTDET_S2_TWO_WAVES", 0);
     h->opt[CD_OPT_RESIZE_ROWS] = env_option("CUTDET_RESIZE_ROWS", 0);
+    h->opt[CD_OPT_F32_BLOCK1_FP32_MFMA] = env_option("CUTDET_F32_BLOCK1_FP32_MFMA", 0);
     ParamOffsets off;
     std::vector<float> img = pack_params(f.data(), &off);
     auto fail = [&](int code) { cd_destroy(h); return code; };
@@ -548,6 +569,7 @@ int cd_create(cd_handle** out, const void* weights_blob, size_t nbytes, int devi
     h->p.w1b = reinterpret_cast<uint16_t*>(base + off.w1b);
     h->p.w2b = reinterpret_cast<uint16_t*>(base + off.w2b); h->p.w3b = reinterpret_cast<uint16_t*>(base + off.w3b);
     h->p.w1s = reinterpret_cast<uint32_t*>(base + off.w1s);
+    h->p.w1x = reinterpret_cast<uint32_t*>(base + off.w1x);
     h->p.w2s = reinterpret_cast<uint32_t*>(base + off.w2s); h->p.w3s = reinterpret_cast<uint32_t*>(base + off.w3s);
 
     const size_t t_int = align_up((size_t)kMaxSrcW * sizeof(int), 256);

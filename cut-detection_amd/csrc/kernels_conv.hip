@@ -783,13 +783,20 @@ __global__ __launch_bounds__(256, 4) void conv1_bf16_kernel(
 // {R, G, B, 0, R, G, B, 0} at (row + ky, col + kq); its B operand is {w'_hi(R, G, B), 0, w'_lo(R, G, B), 0}
 // of tap (ky, kx = kq) (zero for kq = 3): one MFMA per kernel row adds byte x (w'_hi + w'_lo), and
 // every product is exact in the fp32 accumulator.  K = 27 in three MFMAs of 16 cycles each, where
-// fp32 takes seven of 32.  Output cells are split bf16 like the other blocks' inputs.
+// fp32 takes seven of 32.  Output cells are split bf16 like the other blocks' inputs (TERMS = 2).
+//
+// TERMS = 3 is block 1 of the fp32 arithmetic on u8 sources: a third bfloat16 term makes hi + lo + lo2 the
+// fp32 weight w' EXACTLY (3 x 8 mantissa bits), every byte x term product is exact in the fp32 accumulator,
+// and the activations are written as plain fp32 for the fp32 blocks 2 and 3.  Nothing is rounded that the
+// fp32 matrix instructions would not round (they, too, add exact products into fp32 accumulators; only the
+// order of the additions differs), at 6 MFMAs of 16 cycles per tile instead of 7 of 32: the third term costs
+// a second MFMA per kernel row because a pixel's cell has 8 K slots and three terms need 9.
 // ------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256, 3) void conv1_split_kernel(
+template <int MODE, int TERMS>
+__global__ __launch_bounds__(256, TERMS == 3 ? 2 : 3) void conv1_split_kernel(
     const uint8_t* __restrict__ src, SampleArgs sa, int64_t frame_stride, int chan_order,
-    const u32x4* __restrict__ wfrag, const float* __restrict__ post, uint32_t* __restrict__ out,
-    int n, int H, int Hp, int chunks, int stage_pitch) {
+    const u32x4* __restrict__ wfrag, const u32x4* __restrict__ wfrag3, const float* __restrict__ post,
+    uint32_t* __restrict__ out, int n, int H, int Hp, int chunks, int stage_pitch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_stage[];   // MODE 2: two source rows
     __shared__ __attribute__((aligned(16))) u32x4 tile[kC1Rows * kC1RSB];
     __shared__ __attribute__((aligned(16))) float scratch[4 * 16 * 16];   // per-wave 16x16 transposes
@@ -816,11 +823,14 @@ __global__ __launch_bounds__(256, 3) void conv1_split_kernel(
     uint32_t* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
     float* my_out = scratch + wave * 256;
     // B fragments (ky, n-tile) stay in registers; bias and BatchNorm terms go to LDS
-    u32x4 bw[3][3];
+    u32x4 bw[3][3], bw3[TERMS == 3 ? 3 : 1][3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) bw[ky][nt] = wfrag[(ky * 3 + nt) * 64 + lane];
+        for (int nt = 0; nt < 3; ++nt) {
+            bw[ky][nt] = wfrag[(ky * 3 + nt) * 64 + lane];
+            if (TERMS == 3) bw3[ky][nt] = wfrag3[(ky * 3 + nt) * 64 + lane];
+        }
     if (tid < 3 * kC) spost[tid] = post[tid];
 
     if (MODE == 1) point_commit(tile, tid, raw, pcol, bgr);
@@ -864,6 +874,17 @@ __global__ __launch_bounds__(256, 3) void conv1_split_kernel(
                         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t + ky][j]),
                                                                             __builtin_bit_cast(bf16x8, bw[ky][nt]),
                                                                             ky == 0 ? bias4 : acc[t][j], 0, 0, 0);
+            if (TERMS == 3) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t + ky][j]),
+                                                                                __builtin_bit_cast(bf16x8, bw3[ky][nt]),
+                                                                                acc[t][j], 0, 0, 0);
+            }
             const float sc = spost[kC + nt * 16 + ch], sh = spost[2 * kC + nt * 16 + ch];
             float m[4] = {window_max<0>(acc), window_max<1>(acc), window_max<2>(acc), window_max<3>(acc)};
 #pragma unroll
@@ -872,7 +893,7 @@ __global__ __launch_bounds__(256, 3) void conv1_split_kernel(
             __builtin_amdgcn_wave_barrier();
             {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(my_out + (lane >> 2) * 16 + 4 * (lane & 3));
-                if (st_ok) *reinterpret_cast<u32x4*>(st_ptr + nt * 16) = split_bf16(v);
+                if (st_ok) *reinterpret_cast<u32x4*>(st_ptr + nt * 16) = TERMS == 3 ? __builtin_bit_cast(u32x4, v) : split_bf16(v);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read done before the next group rewrites
             __builtin_amdgcn_wave_barrier();
@@ -889,11 +910,15 @@ static int c1_chunks_per_wg(int n, int chunks) {
     return (int)std::min<long>(kC1MaxChunksPerWG, std::max<long>(1, total / 1024));
 }
 
-// static LDS of the block-1 kernel a u8 forward of this arithmetic launches
-static int c1_static_lds(int dtype) {
+// fp32 handles on u8 sources: block 1 as byte x three-term weights on the bf16 matrix pipe (exact, see
+// conv1_split_kernel) unless CD_OPT_F32_BLOCK1_FP32_MFMA asks for the fp32 matrix instructions
+static bool c1_three_terms(const cd_handle* h) { return h->dtype == CD_F32 && !h->opt[CD_OPT_F32_BLOCK1_FP32_MFMA]; }
+
+// static LDS of the block-1 kernel a u8 forward of this handle launches
+static int c1_static_lds(const cd_handle* h) {
     const int common = 4 * 16 * 16 * 4 + 3 * kC * 4;
-    if (dtype == CD_BF16) return kC1Rows * kC1RSB * 8 + common;
-    if (dtype == CD_BF16_SPLIT) return kC1Rows * kC1RSB * 16 + common;
+    if (h->dtype == CD_BF16) return kC1Rows * kC1RSB * 8 + common;
+    if (h->dtype == CD_BF16_SPLIT || c1_three_terms(h)) return kC1Rows * kC1RSB * 16 + common;
     return kC1Tile * 4 + common;
 }
 
@@ -912,10 +937,15 @@ static void launch_conv1(const cd_handle* h, const Workspace& ws, unsigned grid,
                                (const float*)h->p.w1, reinterpret_cast<uint32_t*>(ws.act1), n, g.h, g.h1, chunks, groups, cpw,
                                stage_pitch);
         else
-            hipLaunchKernelGGL((conv1_split_kernel<MODE>), dim3(xcd_grid(n, chunks)), dim3(256), dyn, s, src, sa, frame_stride,
-                               chan_order, reinterpret_cast<const u32x4*>(h->p.w1s), (const float*)h->p.post,
-                               reinterpret_cast<uint32_t*>(ws.act1), n, g.h, g.h1, chunks, stage_pitch);
+            hipLaunchKernelGGL((conv1_split_kernel<MODE, 2>), dim3(xcd_grid(n, chunks)), dim3(256), dyn, s, src, sa, frame_stride,
+                               chan_order, reinterpret_cast<const u32x4*>(h->p.w1s), reinterpret_cast<const u32x4*>(h->p.w1x),
+                               (const float*)h->p.post, reinterpret_cast<uint32_t*>(ws.act1), n, g.h, g.h1, chunks, stage_pitch);
     }
+    else if (MODE != 0 && c1_three_terms(h))
+        hipLaunchKernelGGL((conv1_split_kernel<(MODE == 0 ? 1 : MODE), 3>), dim3(xcd_grid(n, chunks)), dim3(256), dyn, s, src, sa,
+                           frame_stride, chan_order, reinterpret_cast<const u32x4*>(h->p.w1s),
+                           reinterpret_cast<const u32x4*>(h->p.w1x), (const float*)h->p.post,
+                           reinterpret_cast<uint32_t*>(ws.act1), n, g.h, g.h1, chunks, stage_pitch);
     else
         hipLaunchKernelGGL((conv1_kernel<MODE, kF32>), dim3(grid), dim3(256), dyn, s, x, src, sa, frame_stride, chan_order,
                            (const float*)h->p.w1, ws.act1, n, g.h, g.h1, chunks, groups, cpw, stage_pitch);
@@ -947,7 +977,7 @@ int launch_conv1_u8(const cd_handle* h, const Workspace& ws, const ResizeTables&
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     const bool tail_ok = (row_bytes & 15) == 0 || row_stride >= (int64_t)((row_bytes + 15) & ~15);
     if (rt.mode == 1) launch_conv1<1>(h, ws, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
-    else if (aligned && tail_ok && 2 * pitch <= 65536 - c1_static_lds(h->dtype))
+    else if (aligned && tail_ok && 2 * pitch <= 65536 - c1_static_lds(h))
         launch_conv1<2>(h, ws, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw, pitch);
     else launch_conv1<3>(h, ws, xcd_grid(n, groups), s, nullptr, src, sa, frame_stride, chan_order, n, g, chunks, groups, cpw);
     CD_HIP(hipGetLastError());

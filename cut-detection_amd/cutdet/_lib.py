@@ -22,7 +22,7 @@ CD_BF16 = 1
 CD_BF16_SPLIT = 2
 DTYPES = {"f32": CD_F32, "bf16": CD_BF16, "bf16_split": CD_BF16_SPLIT}
 CD_BGR, CD_RGB = 0, 1
-OPTIONS = {"range_by_stage": 0, "fuse_blocks12": 1, "range_one_stream": 2, "split_two_waves": 3, "resize_rows": 4}
+OPTIONS = {"range_by_stage": 0, "fuse_blocks12": 1, "range_one_stream": 2, "split_two_waves": 3, "resize_rows": 4, "f32_block1_fp32_mfma": 5}
 STAGES = ("preprocess", "conv1", "conv2", "conv3_head", "rle")
 
 _h = C.c_void_p

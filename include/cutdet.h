@@ -192,9 +192,16 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
  *                           LDS, so its workgroups find room on a CU beside the convolution kernels'.
  *                           1: one workgroup per output row stages the two source rows in LDS (needs
  *                           16-byte aligned rows; used anyway when the default kernel does not apply: output
- *                           widths that are not a multiple of 4, rows shorter than 8 bytes). */
+ *                           widths that are not a multiple of 4, rows shorter than 8 bytes).
+ *   CD_OPT_F32_BLOCK1_FP32_MFMA  CD_F32 handles, u8 sources.  0 (default): block 1 multiplies the frame's bytes (exact in
+ *                           bfloat16) with the fp32 weights written as three bfloat16 terms (hi + lo + lo2 == w
+ *                           exactly) on v_mfma_f32_16x16x32_bf16: exact products, fp32 accumulation - what the fp32
+ *                           matrix instructions compute, in another order of additions and a third of the time.
+ *                           1: block 1 on v_mfma_f32_16x16x4_f32 as well.  This option changes low-order bits of
+ *                           the logits (both settings agree with the reference to < 1e-5); cd_forward (float
+ *                           frames) always uses the fp32 instructions. */
 enum { CD_OPT_RANGE_BY_STAGE = 0, CD_OPT_FUSE_BLOCKS12 = 1, CD_OPT_RANGE_ONE_STREAM = 2, CD_OPT_SPLIT_TWO_WAVES = 3,
-       CD_OPT_RESIZE_ROWS = 4, CD_OPT_COUNT = 5 };
+       CD_OPT_RESIZE_ROWS = 4, CD_OPT_F32_BLOCK1_FP32_MFMA = 5, CD_OPT_COUNT = 6 };
 int cd_set_option(cd_handle* h, int option, int value);
 
 /* cd_forward_u8 for callers that cannot allocate device memory (code under HIP graph capture, tight

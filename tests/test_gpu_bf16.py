@@ -169,7 +169,10 @@ def test_random_weights_including_negative_batchnorm_scales(oracle_weights):
         xu = eng.preprocess(frames.cuda())
         a, b = eng.forward(xu).cpu(), eng.forward_u8(frames.cuda())[0].cpu()
         if dtype == "f32":
-            assert torch.equal(a, b)             # fused resize = resize then forward, bit for bit
+            # default block 1 of u8 sources: three exact weight terms on the bf16 pipe, a few ulp from the float entry
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, scale)
+            eng.set_option("f32_block1_fp32_mfma", 1)
+            assert torch.equal(a, eng.forward_u8(frames.cuda())[0].cpu())   # fused resize = resize then forward, bit for bit
         else:
             assert float((a - b).abs().max()) <= tol * max(1.0, scale)   # the fused path rounds the same pixels to bf16
         eng.close()

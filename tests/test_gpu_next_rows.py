@@ -61,9 +61,14 @@ def test_load_and_glue_nets_on_the_reference_files_gives_golden_logits(golden_di
     logits, _, am = net.classify_frames(frames)
     assert np.abs(logits.cpu().numpy() - g[f"logits_{case}"]).max() <= 1e-3
     assert am.cpu().tolist() == m["classes"]
-    # the float entry the reference's driver uses: net(batch)
+    # the float entry the reference's driver uses: net(batch).  Its block 1 runs on the fp32 matrix instructions
+    # (float frames are not bytes); the u8 entry agrees with it bit for bit under the same setting and to a few
+    # ulp with its default block 1 (three exact weight terms on the bf16 pipe)
     y = net(net.engine.preprocess(frames)).cpu().numpy()
-    assert y.tobytes() == logits.cpu().numpy().tobytes()
+    assert np.abs(y - logits.cpu().numpy()).max() <= 2e-5
+    net.engine.set_option("f32_block1_fp32_mfma", 1)
+    assert y.tobytes() == net.classify_frames(frames)[0].cpu().numpy().tobytes()
+    net.engine.set_option("f32_block1_fp32_mfma", 0)
 
 
 def test_evaluate_matches_the_validation_loop(engine):
@@ -91,7 +96,7 @@ def test_evaluate_matches_the_validation_loop(engine):
     # float frames as the reference loader's dicts give the same counts
     x = engine.preprocess(dev_frames)
     got2 = net.evaluate({"x": x[a:b], "y": torch.from_numpy(labels[a:b])} for a, b in bounds)
-    assert got2["correct"] == got["correct"] and abs(got2["loss"] - got["loss"]) <= 1e-9
+    assert got2["correct"] == got["correct"] and abs(got2["loss"] - got["loss"]) <= 1e-6   # block 1: other order of additions
     # labels outside the class range are skipped
     bad = torch.tensor([0, 7, -1, 2])
     got3 = net.evaluate([(dev_frames[[0, 1, 2, 40]], bad)])

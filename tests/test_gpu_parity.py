@@ -26,6 +26,23 @@ def engine():
 
 
 @pytest.fixture(scope="module")
+def fp32_mfma_engine():
+    """fp32 with block 1 on the fp32 matrix instructions as well (CD_OPT_F32_BLOCK1_FP32_MFMA): the setting under
+    which the u8 entries and the float entry run the same arithmetic and agree bit for bit.  The default puts
+    block 1 of u8 sources on the bf16 matrix pipe with three exact weight terms (other order of additions)."""
+    from cutdet import api
+    from cutdet.engine import Engine
+    eng = Engine(api.default_blob(), torch.device("cuda:0"), "f32")
+    eng.set_option("f32_block1_fp32_mfma", 1)
+    yield eng
+    eng.close()
+
+
+# what the two block-1 formulations of the fp32 arithmetic may differ by (measured: <= 4e-6)
+BLOCK1_FORMULATIONS_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
 def oracle_weights():
     from oracle import net as onet
     return onet.load_blob()
@@ -87,7 +104,7 @@ def test_forward_matches_reference_logits_uniform_input(engine, golden_dir):
 
 
 @pytest.mark.parametrize("case", ["720p", "1080p", "180p", "4x3"])
-def test_forward_u8_matches_reference_logits(engine, golden_dir, case):
+def test_forward_u8_matches_reference_logits(engine, fp32_mfma_engine, golden_dir, case):
     from oracle import synth
     g = np.load(os.path.join(golden_dir, "net_golden.npz"))
     with open(os.path.join(golden_dir, "net_golden_meta.json")) as f:
@@ -99,26 +116,36 @@ def test_forward_u8_matches_reference_logits(engine, golden_dir, case):
     assert err <= LOGIT_TOL, err
     assert am.cpu().tolist() == m["classes"]
     assert (mx.cpu().numpy() == y.max(axis=1)).all()
-    # two-kernel route (preprocess, then forward) gives the same bits as the fused route
-    y2 = engine.forward(engine.preprocess(frames)).cpu().numpy()
-    assert y2.tobytes() == y.tobytes()
+    # block 1 on the fp32 matrix instructions: also inside the contract, a few ulp from the default
+    ys = fp32_mfma_engine.forward_u8(frames)[0].cpu().numpy()
+    assert np.abs(ys - g[f"logits_{case}"]).max() <= LOGIT_TOL
+    assert np.abs(ys - y).max() <= BLOCK1_FORMULATIONS_TOL
+    # and then the two-kernel route (preprocess, then forward) gives the same bits as the fused route
+    y2 = fp32_mfma_engine.forward(fp32_mfma_engine.preprocess(frames)).cpu().numpy()
+    assert y2.tobytes() == ys.tobytes()
+    y3 = engine.forward(engine.preprocess(frames)).cpu().numpy()             # the float entry ignores the option
+    assert y3.tobytes() == y2.tobytes()
 
 
 @pytest.mark.parametrize("h,w,pad", [(90, 161, 0), (180, 320, 5), (1080, 1920, 16), (100, 300, 0)])
-def test_fused_general_resize_row_layouts(engine, h, w, pad):
+def test_fused_general_resize_row_layouts(engine, fp32_mfma_engine, h, w, pad):
     """The fused general resize has two staging routes: source rows through LDS (16-byte aligned
     rows) and per-thread gathers (anything else: odd widths, views at odd offsets).  Both must give
-    the bits of the two-kernel route, whose resize is checked byte for byte against the oracle."""
+    the bits of the two-kernel route, whose resize is checked byte for byte against the oracle - with
+    block 1 on the fp32 matrix instructions; the default block 1 (three-term weights on the bf16 pipe) has
+    the same two routes and must give the same bits on either."""
     from oracle import synth
     frames = torch.from_numpy(synth.clip(SEED, [0, 1, 2, 1, 0], h, w)).to(engine.device)
-    want = engine.forward(engine.preprocess(frames))
+    want = fp32_mfma_engine.forward(fp32_mfma_engine.preprocess(frames))
+    want_default = engine.forward_u8(frames)[0]
     if pad:
         wide = torch.zeros((5, h, w + pad + 1, 3), dtype=torch.uint8, device=engine.device)
         view = wide[:, :, 1:w + 1] if pad % 16 else wide[:, :, :w]      # odd pads: rows start off 16-byte boundaries
         view.copy_(frames)
         frames = view
-    got = engine.forward_u8(frames)[0]
-    assert torch.equal(got, want)
+    assert torch.equal(fp32_mfma_engine.forward_u8(frames)[0], want)
+    assert torch.equal(engine.forward_u8(frames)[0], want_default)
+    assert float((want_default - want).abs().max()) <= BLOCK1_FORMULATIONS_TOL
 
 
 def test_forward_matches_oracle_mixed_batch(engine, oracle_weights):

@@ -29,7 +29,7 @@ import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
 line = "%-22s %10.0f f/s  ms/step %8.3f  conv2 %.4f ms frac %.4f  whole-net %.3f" % (
     sys.argv[2], d["value"], d["ms_per_step"], r["launch_ms"], r["frac"], r["whole_net_frac_of_mfma_peak"])
-for k in ("config4", "strong_200k", "independent_clips"):
+for k in ("fp32_mfma_block1", "config4", "strong_200k", "independent_clips"):
     if k in d:
         line += "  %s %.0f f/s" % (k, d[k]["value"])
 if d.get("cpu_baseline"):
