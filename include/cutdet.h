@@ -63,7 +63,11 @@ enum {
     CD_STAGE_COUNT = 5
 };
 
-/* Arithmetic type of the forward pass.  CD_F32: everything in fp32 (what the reference computes).
+/* Arithmetic type of the forward pass.  CD_F32: everything in fp32 (what the reference computes): exact
+ * products accumulated in fp32.  Blocks 2 and 3 and the head use the fp32 matrix instructions; block 1 of u8
+ * frames gets the same exact products from the bf16 matrix cores - a byte is exact in bfloat16 and the fp32
+ * weight is written as three bfloat16 terms that sum to it exactly - unless CD_OPT_F32_BLOCK1_FP32_MFMA
+ * (cd_set_option) asks for the fp32 instructions there too.
  * CD_BF16: the three convolutions multiply bfloat16 inputs/activations and weights on the bf16
  * matrix cores with fp32 accumulation; bias, pooling/affine epilogues and the head stay fp32.
  * Logits then differ from the fp32 result by a few 1e-2; class ids are unchanged on inputs with
@@ -168,10 +172,10 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
                         int net_h, int net_w,
                         float* logits, float* maxv, int64_t* argmax, void* stream);
 
-/* How cd_forward_u8_range schedules its work; every setting gives the same bits.  No counterpart in the
+/* How cd_forward_u8_range schedules its work; every setting but the last gives the same bits.  No counterpart in the
  * reference.  The defaults can also be set through the environment when a handle is created
- * (CUTDET_RANGE_MODE, CUTDET_FUSED12, CUTDET_RANGE_ONE_STREAM, CUTDET_S2_TWO_WAVES, CUTDET_RESIZE_ROWS = 0 or 1).
- * CD_OPT_SPLIT_TWO_WAVES and CD_OPT_RESIZE_ROWS apply to every entry point that runs those kernels, not
+ * (CUTDET_RANGE_MODE, CUTDET_FUSED12, CUTDET_RANGE_ONE_STREAM, CUTDET_S2_TWO_WAVES, CUTDET_RESIZE_ROWS,
+ * CUTDET_F32_BLOCK1_FP32_MFMA = 0 or 1).  CD_OPT_SPLIT_TWO_WAVES, CD_OPT_RESIZE_ROWS and CD_OPT_F32_BLOCK1_FP32_MFMA apply to every entry point that runs those kernels, not
  * only to the range call.
  *   CD_OPT_RANGE_BY_STAGE   0 (default): whole batches alternate between the two streams.  1: block 1
  *                           of every batch on one stream, blocks 2 + 3 on the other.
