@@ -81,7 +81,7 @@ struct DeviceParams {
     uint16_t* w1b;  // conv1 B fragments in bf16: [3 ky][3 n-tiles][64 lanes][4] (kx = lane>>4, channel e; zero pads)
     uint16_t* w2b;  // conv2 / conv3 B fragments in bf16: [27 steps][3 n-tiles][64 lanes][4]
     uint16_t* w3b;
-    uint32_t* w1x;  // the third term of the same weights, [3 ky][3 n-tiles][64 lanes][lo2(R,G,B),0, 0,0,0,0]
+    uint32_t* w1x;  // the third term of the same weights, [2][3 n-tiles][64 lanes]: {lo2 row 0, lo2 row 1} and {lo2 row 2, 0}
     uint32_t* w1s;  // conv1 B fragments for split bf16: [3 ky][3 n-tiles][64 lanes][hi(R,G,B),0, lo(R,G,B),0] of w / 255
     uint32_t* w2s;  // conv2 / conv3 B fragments as split bf16: [27 steps][3 n-tiles][64 lanes][hi x 4, lo x 4]
     uint32_t* w3s;

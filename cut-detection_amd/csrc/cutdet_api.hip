@@ -188,13 +188,15 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
                         cell[4 + e] = bf16_rne(w - hf);
                     }
     }
-    // the third term of the same weights, {lo2(w'[ci=0..2]), 0, 0, 0, 0, 0}: hi + lo + lo2 == w' exactly (3 x 8 mantissa
-    // bits; the remainder after each term is computed exactly in fp32)
-    const size_t o_w1x = section(9 * 64 * 4);
+    // the third term of the same weights: hi + lo + lo2 == w' exactly (3 x 8 mantissa bits; the remainder after each
+    // term is computed exactly in fp32).  Fragment (0, nt): {lo2 of kernel row 0, lo2 of kernel row 1}; fragment
+    // (1, nt): {lo2 of kernel row 2, 0} - the operand they meet holds the pixels of two kernel rows
+    const size_t o_w1x = section(6 * 64 * 4);
     {
         uint16_t* d = reinterpret_cast<uint16_t*>(&img[o_w1x]);
         const uint16_t* two = reinterpret_cast<const uint16_t*>(&img[o_w1s]);
         auto as_float = [](uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        std::memset(d, 0, (size_t)6 * 64 * 16);
         for (int ky = 0; ky < 3; ++ky)
             for (int nt = 0; nt < 3; ++nt)
                 for (int lane = 0; lane < 64; ++lane)
@@ -203,9 +205,7 @@ std::vector<float> pack_params(const float* f, ParamOffsets* off) {
                         const float w = (kx < 3 && e < 3) ? cv[0].w[oc * 27 + e * 9 + ky * 3 + kx] / 255.0f : 0.f;
                         const uint16_t* c2 = two + ((ky * 3 + nt) * 64 + lane) * 8;
                         const float rest = (w - as_float(c2[e])) - as_float(c2[4 + e]);
-                        uint16_t* cell = d + ((ky * 3 + nt) * 64 + lane) * 8;
-                        cell[e] = bf16_rne(rest);
-                        cell[4 + e] = 0;
+                        d[(((ky >> 1) * 3 + nt) * 64 + lane) * 8 + 4 * (ky & 1) + e] = bf16_rne(rest);
                     }
     }
     for (int l = 0; l < 3; ++l) {

@@ -789,8 +789,9 @@ __global__ __launch_bounds__(256, 4) void conv1_bf16_kernel(
 // fp32 weight w' EXACTLY (3 x 8 mantissa bits), every byte x term product is exact in the fp32 accumulator,
 // and the activations are written as plain fp32 for the fp32 blocks 2 and 3.  Nothing is rounded that the
 // fp32 matrix instructions would not round (they, too, add exact products into fp32 accumulators; only the
-// order of the additions differs), at 6 MFMAs of 16 cycles per tile instead of 7 of 32: the third term costs
-// a second MFMA per kernel row because a pixel's cell has 8 K slots and three terms need 9.
+// order of the additions differs), at 5 MFMAs of 16 cycles per tile instead of 7 of 32: a pixel's cell has 8 K
+// slots, {R, G, B, 0} twice, which meet {hi, lo} in one MFMA per kernel row; the third term needs the pixel once,
+// so two kernel rows' pixels share an operand there (rows 0 + 1 in one MFMA, row 2 in another).
 // ------------------------------------------------------------------------------------------
 template <int MODE, int TERMS>
 __global__ __launch_bounds__(256, TERMS == 3 ? 2 : 3) void conv1_split_kernel(
@@ -823,13 +824,14 @@ __global__ __launch_bounds__(256, TERMS == 3 ? 2 : 3) void conv1_split_kernel(
     uint32_t* fout = out + (int64_t)frame * (Hp + 2) * kP1W * kC;
     float* my_out = scratch + wave * 256;
     // B fragments (ky, n-tile) stay in registers; bias and BatchNorm terms go to LDS
-    u32x4 bw[3][3], bw3[TERMS == 3 ? 3 : 1][3];
+    // third term: fragment 0 = {lo2 of kernel row 0, lo2 of kernel row 1}, fragment 1 = {lo2 of kernel row 2, 0}
+    u32x4 bw[3][3], bw3[TERMS == 3 ? 2 : 1][3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             bw[ky][nt] = wfrag[(ky * 3 + nt) * 64 + lane];
-            if (TERMS == 3) bw3[ky][nt] = wfrag3[(ky * 3 + nt) * 64 + lane];
+            if (TERMS == 3 && ky < 2) bw3[ky][nt] = wfrag3[(ky * 3 + nt) * 64 + lane];
         }
     if (tid < 3 * kC) spost[tid] = post[tid];
 
@@ -860,6 +862,15 @@ __global__ __launch_bounds__(256, TERMS == 3 ? 2 : 3) void conv1_split_kernel(
         for (int r = 0; r < 5; ++r)
 #pragma unroll
             for (int j = 0; j < 3; ++j) a[r][j] = tile[base[j] + r * kC1RSB];
+        // third term: the pixels of kernel rows 0 and 1 share an operand (each cell's second half only repeats
+        // its first), so the term costs two MFMAs per tile, not three
+        u32x4 a01[TERMS == 3 ? 3 : 1][3];
+        if (TERMS == 3) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a01[t][j] = u32x4{a[t][j][0], a[t][j][1], a[t + 1][j][0], a[t + 1][j][1]};
+        }
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const float bias = spost[nt * 16 + ch];
@@ -876,14 +887,19 @@ __global__ __launch_bounds__(256, TERMS == 3 ? 2 : 3) void conv1_split_kernel(
                                                                             ky == 0 ? bias4 : acc[t][j], 0, 0, 0);
             if (TERMS == 3) {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
+                    for (int j = 0; j < 3; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a01[t][j]),
+                                                                            __builtin_bit_cast(bf16x8, bw3[0][nt]),
+                                                                            acc[t][j], 0, 0, 0);
 #pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t + ky][j]),
-                                                                                __builtin_bit_cast(bf16x8, bw3[ky][nt]),
-                                                                                acc[t][j], 0, 0, 0);
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[t + 2][j]),
+                                                                            __builtin_bit_cast(bf16x8, bw3[1][nt]),
+                                                                            acc[t][j], 0, 0, 0);
             }
             const float sc = spost[kC + nt * 16 + ch], sh = spost[2 * kC + nt * 16 + ch];
             float m[4] = {window_max<0>(acc), window_max<1>(acc), window_max<2>(acc), window_max<3>(acc)};
