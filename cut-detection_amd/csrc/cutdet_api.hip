@@ -831,15 +831,16 @@ int cd_forward_u8_range(cd_handle* h, const uint8_t* src, int64_t n, int batch, 
     const int64_t small_row = (int64_t)net_w * 3, small_frame = small_row * net_h;
     const int mode = fused12 ? 0 : h->opt[CD_OPT_RANGE_BY_STAGE];
     const bool one_stream = h->opt[CD_OPT_RANGE_ONE_STREAM] != 0;
-    // fp32 with a resize pass over large frames: the memory-bound resize beside ONE stream of
-    // matrix-bound classification measured faster than beside two (1080p: 402 k against 363 k
-    // frames/s), small frames the other way round (320x180: 424 k against 442 k); the bf16 arithmetics,
-    // whose kernels are short, gain from the second classification stream at every size
+    // Two classification streams at every size.  (While fp32's block 1 ran on the fp32 matrix instructions and the
+    // resize pass held LDS, 1080p fp32 was faster with one: 402 k against 363 k frames/s.  With block 1 on the bf16
+    // pipe and the LDS-free resize it is the other way round, 523 k against 504 k at batch 256; that remains true
+    // with CD_OPT_F32_BLOCK1_FP32_MFMA only for small frames, so the old rule is kept for that setting.)
     const bool large_frames = (int64_t)H0 * W0 * 3 > (2 << 20);
+    const bool one_cls_rule = two_pass && h->dtype == CD_F32 && h->opt[CD_OPT_F32_BLOCK1_FP32_MFMA] && large_frames;
 #ifdef CD_EXP_ENV
-    const bool two_cls = std::getenv("CUTDET_X_ONE_CLS") ? false : !(two_pass && h->dtype == CD_F32 && large_frames);
+    const bool two_cls = std::getenv("CUTDET_X_ONE_CLS") ? false : std::getenv("CUTDET_X_TWO_CLS") ? true : !one_cls_rule;
 #else
-    const bool two_cls = !(two_pass && h->dtype == CD_F32 && large_frames);
+    const bool two_cls = !one_cls_rule;
 #endif
     // split bf16 beside a resize pass that saturates HBM: block 2 asks for its weights 8 steps ahead instead
     // of 2 (interleaved A/B at 1080p: +2.9 %; at 720p and 320x180, where nothing streams beside it, -0.5 %)
