@@ -77,7 +77,11 @@ template <> struct Prec<kBF16> {
 };
 template <> struct Prec<kS2> {
     typedef uint32_t elem; typedef u32x4 frag; typedef SplitB bfrag;   // element = one channel's (hi, lo), by size only
+#ifdef CD_EXP_S2_SUB       // timing experiment: more MFMAs per fragment pair (what three-term activations would issue)
+    static constexpr int kSub = CD_EXP_S2_SUB;
+#else
     static constexpr int kSub = 2;
+#endif
     static constexpr int kEs = 4;
 #ifdef CD_S2_WDUP
     static constexpr int kWBytes = 32;
