@@ -28,6 +28,22 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.cd_version() == 3
 
 
+def test_option_names_follow_the_header():
+    """The Python names of cd_set_option's options are the header's CD_OPT_* enumerators, same numbers;
+    dtype and stage constants likewise."""
+    from cutdet import _lib
+    text = open(os.path.join(ROOT, "include", "cutdet.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    opts = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"CD_OPT_([A-Z0-9_]+)\s*=\s*(\d+)", code)}
+    count = opts.pop("count")
+    assert opts == _lib.OPTIONS and count == len(opts) == max(opts.values()) + 1
+    for name in opts:                      # every option is documented where it is declared
+        assert f"CD_OPT_{name.upper()}" in text.split("enum { CD_OPT_RANGE_BY_STAGE")[0]
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(CD_[A-Z0-9_]+)\s*=\s*(-?\d+)", code)}
+    for name in ("CD_OK", "CD_EINVAL", "CD_ECAP", "CD_BGR", "CD_RGB"):
+        assert getattr(_lib, name) == consts[name], name
+
+
 def test_create_rejects_garbage_without_touching_the_gpu():
     from cutdet import _lib
     h = C.c_void_p(0)
