@@ -3,6 +3,8 @@
 #
 #   tools/gpu.sh tests [pytest args]        the GPU suite in one process (default: all of tests/), then the
 #                                           allocation-free test alone in a fresh process
+#   tools/gpu.sh tests-options              the whole GPU suite once per alternative kernel / schedule, selected through the
+#                                           handles' environment defaults (CUTDET_RESIZE_ROWS, CUTDET_S2_TWO_WAVES, ...)
 #   tools/gpu.sh one <pytest args>          one pytest target, output shown (-s)
 #   tools/gpu.sh bench NAME [bench args]    python bench.py [args] -> gpurun_out/bench/NAME.json (+ one summary line)
 #   tools/gpu.sh profile NAME "TRACE ARGS" "PMC ARGS"
@@ -39,6 +41,14 @@ PY
 }
 
 case "$MODE" in
+tests-options)
+  for e in CUTDET_RESIZE_ROWS=1 CUTDET_S2_TWO_WAVES=1 CUTDET_F32_BLOCK1_FP32_MFMA=1 CUTDET_FUSED12=1 CUTDET_RANGE_MODE=1; do
+    echo "== $e"
+    env $e timeout -k 10 600 python3 -u -m pytest tests -x -q --timeout 600 --timeout-method thread -m gpu -p no:cacheprovider \
+      > gpurun_out/suite_$e.log 2>&1 || { tail -40 gpurun_out/suite_$e.log; exit 1; }
+    tail -1 gpurun_out/suite_$e.log
+  done
+  ;;
 ablate)
   LIBV=$PWD/cut-detection_amd/lib/variants/libcutdet_skip.so
   [ -f "$LIBV" ] || { echo "build the skip variant first (see the header of this script)"; exit 1; }
